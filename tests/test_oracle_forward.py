@@ -1,0 +1,112 @@
+"""The torch oracle vs goldens produced by running the reference's own get_output graph
+code on the numpy TF-1.8 shim (oracle/make_golden.py); plus gradient / optimizer
+self-checks of the oracle (finite differences in float64, TF-Adam closed form)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import shapes, waveunet_torch as wt
+from oracle.golden_params import GOLDEN_CASES, golden_params
+
+
+def _cfg(case):
+    return shapes.finalize_config(dict(shapes.BASE_MODEL_CONFIG, **case["cfg"]))
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN_CASES))
+def test_forward_matches_reference_graph(name, golden_dir):
+    case = GOLDEN_CASES[name]
+    cfg = _cfg(case)
+    g = np.load(os.path.join(golden_dir, "fwd_%s.npz" % name))
+    params = golden_params(cfg, case["seed"])
+    # float64: the oracle must agree with the reference graph to rounding
+    tp = wt.params_to_torch(params, torch.float64)
+    outs = wt.get_output(cfg, tp, torch.tensor(g["mix"], dtype=torch.float64), case["training"])
+    assert list(outs.keys()) == cfg["source_names"]
+    for n in cfg["source_names"]:
+        ref = g["out_" + n]
+        got = outs[n].numpy()
+        assert got.shape == ref.shape
+        assert np.max(np.abs(got - ref)) <= 1e-11 * max(1.0, np.abs(ref).max()), n
+    # float32 (the dtype the HIP path and the timed CPU baseline run in)
+    tp32 = wt.params_to_torch(params, torch.float32)
+    outs32 = wt.get_output(cfg, tp32, torch.tensor(g["mix"]), case["training"])
+    for n in cfg["source_names"]:
+        assert np.max(np.abs(outs32[n].numpy() - g["out_" + n])) <= 2e-5, n
+
+
+def test_mix_consistency_of_difference_output():
+    # OutputLayer.py:20-22: sources sum to the (cropped) mix in training mode
+    case = GOLDEN_CASES["full_multi_small"]
+    cfg = _cfg(case)
+    params = wt.params_to_torch(golden_params(cfg, 3), torch.float64)
+    i, o = shapes.get_padding(cfg, [2, 40, 0])
+    mix, _ = wt.synthetic_batch(cfg, 2, i[1], o[1], seed=5)
+    outs = wt.get_output(cfg, params, torch.tensor(mix, dtype=torch.float64), True)
+    total = sum(outs[n] for n in cfg["source_names"])
+    pad = (i[1] - o[1]) // 2
+    assert torch.allclose(total, torch.tensor(mix, dtype=torch.float64)[:, pad:i[1] - pad, :],
+                          atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["baseline_small", "full_small", "learned_same_small",
+                                  "odd_filters_small"])
+def test_gradients_by_finite_differences(name):
+    case = GOLDEN_CASES[name]
+    cfg = _cfg(case)
+    B = 1
+    i, o = shapes.get_padding(cfg, [B, case["frames"], 0])
+    mix, targets = wt.synthetic_batch(cfg, B, i[1], o[1], seed=7)
+    tmix = torch.tensor(mix, dtype=torch.float64)
+    ttg = {k: torch.tensor(v, dtype=torch.float64) for k, v in targets.items()}
+    tp = wt.params_to_torch(golden_params(cfg, case["seed"]), torch.float64, requires_grad=True)
+    loss, grads = wt.train_step(cfg, tp, tmix, ttg)
+    rng = np.random.RandomState(0)
+    eps = 1e-6
+    for idx in rng.choice(len(tp), size=min(8, len(tp)), replace=False):
+        p = tp[idx][1]
+        flat = p.detach().view(-1)
+        j = int(rng.randint(flat.numel()))
+        old = float(flat[j])
+        with torch.no_grad():
+            flat[j] = old + eps
+            lp = float(wt.separator_loss(cfg, wt.get_output(cfg, tp, tmix, True), ttg))
+            flat[j] = old - eps
+            lm = float(wt.separator_loss(cfg, wt.get_output(cfg, tp, tmix, True), ttg))
+            flat[j] = old
+        fd = (lp - lm) / (2 * eps)
+        an = float(grads[idx].view(-1)[j])
+        assert abs(fd - an) <= 1e-6 * max(1.0, abs(an)) + 1e-9, (tp[idx][0], fd, an)
+
+
+def test_tf_adam_rule():
+    # closed form for one and two steps (epsilon outside the bias correction)
+    p = [torch.tensor([1.0, -2.0], dtype=torch.float64)]
+    g = [torch.tensor([0.5, -0.25], dtype=torch.float64)]
+    m = [torch.zeros(2, dtype=torch.float64)]
+    v = [torch.zeros(2, dtype=torch.float64)]
+    wt.tf_adam_step(p, g, m, v, 1, 1e-2)
+    lr_t = 1e-2 * math.sqrt(1 - 0.999) / (1 - 0.9)
+    mm = 0.1 * np.array([0.5, -0.25])
+    vv = 0.001 * np.array([0.25, 0.0625])
+    want = np.array([1.0, -2.0]) - lr_t * mm / (np.sqrt(vv) + 1e-8)
+    assert np.allclose(p[0].numpy(), want, rtol=0, atol=1e-15)
+    # differs from torch.optim.Adam's epsilon placement by construction
+    q = torch.nn.Parameter(torch.tensor([1.0, -2.0], dtype=torch.float64))
+    q.grad = g[0].clone()
+    torch.optim.Adam([q], lr=1e-2, eps=1e-8).step()
+    assert np.allclose(q.detach().numpy(), want, atol=1e-6)
+    assert not np.array_equal(q.detach().numpy(), want)
+
+
+def test_synthetic_batch_contract():
+    cfg = _cfg(GOLDEN_CASES["full_multi_small"])
+    mix, tg = wt.synthetic_batch(cfg, 2, 283, 45, seed=1)
+    assert mix.shape == (2, 283, 2) and mix.dtype == np.float32
+    assert list(tg.keys()) == cfg["source_names"]
+    for v in tg.values():
+        assert v.shape == (2, 45, 2)
+    assert np.abs(mix).max() <= 1.0
