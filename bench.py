@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Headline benchmark: waveform samples/sec, forward + backward (+ Adam, + gradient all-reduce
+when N > 1) of the M1 12-level Wave-U-Net at BASELINE.json configs[1]: fp32, batch 16 per GPU,
+~147k-sample context input (147443 -> 16389 samples), synthetic waveforms resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py ...`)
+
+One "step" = one `sess.run([separator_solver, ...])` of /root/reference/Training.py:105:
+get_output, MSE loss, full backward, TF-Adam update.  Rank 0 prints ONE JSON line.
+`value` = output samples/s of the whole job (N * B * Tout * K / max-over-ranks time);
+the input-sample rate (N * B * Tin) is reported in `config` for reference.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+import torch.distributed as dist   # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA = fp32 vector peak
+
+
+def cpu_baseline(cfg_name, cfg_over, budget_s=12.0):
+    """The oracle (torch-CPU fp32 restatement of the reference graph; TensorFlow 1.8 cannot be
+    installed) timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle import shapes, waveunet_torch as wt       # checker / CPU baseline only
+    ocfg = shapes.finalize_config(dict(shapes.BASE_MODEL_CONFIG, **cfg_over))
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B = 2
+    i, o = shapes.get_padding(ocfg, [B, ocfg["num_frames"], 0])
+    mix, targets = wt.synthetic_batch(ocfg, B, i[1], o[1], seed=1337)
+    tp = wt.params_to_torch(wt.init_params(ocfg, 1337), torch.float32, requires_grad=True)
+    m = [torch.zeros_like(p) for _, p in tp]
+    v = [torch.zeros_like(p) for _, p in tp]
+    tmix = torch.from_numpy(mix)
+    ttg = {k: torch.from_numpy(x) for k, x in targets.items()}
+    wt.train_step(ocfg, tp, tmix, ttg, m, v, 1, 1e-4)      # warm-up
+    t0 = time.time()
+    n = 0
+    while n < 2 or (time.time() - t0 < budget_s and n < 20):
+        wt.train_step(ocfg, tp, tmix, ttg, m, v, n + 2, 1e-4)
+        n += 1
+    dt = (time.time() - t0) / n
+    return {"value": B * o[1] / dt, "unit": "output samples/s", "cores": cores, "kind": "port",
+            "sample": "%d steps of batch %d (of 16) excerpts %d->%d, torch-CPU fp32 oracle, fwd+bwd+Adam, %.2f s/step"
+                      % (n, B, i[1], o[1], dt),
+            "threads": torch.get_num_threads()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="m1_context")
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import wave_u_net_amd as wun
+    from wave_u_net_amd import _lib
+    from wave_u_net_amd.training import Trainer, synthetic_source
+
+    cfg = wun.get_config(args.config)
+    tr = Trainer(cfg, batch_size=args.batch)
+    world = tr.world
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    source = synthetic_source(cfg, tr.batch, tr.t_in, tr.t_out, tr.device, seed=1337 + tr.rank)
+    mix, targets = source()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        loss = tr.step(mix, targets)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tr.step(mix, targets)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=tr.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_val = float(loss.item())
+
+    info = tr.sep.plan_info()
+    ms_per_step = 1e3 * elapsed / args.steps
+    out_samples = world * tr.batch * tr.t_out
+    result = {
+        "metric": "waveform samples/sec fwd+bwd, M1 12-level Wave-U-Net @1/2/4/8 GPU",
+        "value": out_samples * args.steps / elapsed,
+        "unit": "output samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[1]: M1 (12 levels, 24 ch, 15/5 filters, mono) with context, "
+                               "fwd+bwd+Adam, batch %d/GPU, %d -> %d samples" % (tr.batch, tr.t_in, tr.t_out),
+                   "named_config": args.config, "global_batch": world * tr.batch,
+                   "input_frames": tr.t_in, "output_frames": tr.t_out,
+                   "input_samples_per_s": world * tr.batch * tr.t_in * args.steps / elapsed,
+                   "parallelism": "dp%d" % world, "final_loss": loss_val,
+                   "step_tflops_executed": (info.fwd_flops + info.bwd_flops) / 1e12,
+                   "step_tflops_reference_graph": 3.0 * info.fwd_flops_dense / 1e12,
+                   "achieved_tflops_executed": (info.fwd_flops + info.bwd_flops) / (ms_per_step * 1e9)},
+    }
+
+    if not args.no_roofline:
+        # a few extra steps with HIP events around every heavy launch (all ranks step together,
+        # rank 0 records): kept outside the timed region so the events do not perturb `value`
+        lib = _lib.load()
+        nprof = 2
+        if tr.rank == 0:
+            lib.wun_profile_begin()
+        for _ in range(nprof):
+            tr.step(mix, targets)
+        torch.cuda.synchronize()
+        if tr.rank == 0:
+            buf = ctypes.create_string_buffer(1 << 16)
+            _lib.check(lib.wun_profile_end(buf, len(buf)))
+            kernels = json.loads(buf.value.decode())["kernels"]
+            kernels.sort(key=lambda k: -k["ms"])
+            top = kernels[0]
+            avg_ms = top["ms"] / top["launches"]
+            achieved = top["flops"] / top["launches"] / (avg_ms * 1e-3) / 1e12
+            result["roofline"] = {
+                "bound": "mfma", "kernel": top["name"], "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                "avg_launch_ms": avg_ms, "launches_per_step": top["launches"] / nprof,
+                "flops_per_launch": top["flops"] / top["launches"],
+                "kernel_ms_per_step": {k["name"]: k["ms"] / nprof for k in kernels},
+                "kernel_tflops": {k["name"]: k["flops"] / (k["ms"] * 1e-3) / 1e12 for k in kernels if k["ms"] > 0},
+            }
+
+    if tr.rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.config, wun.NAMED_CONFIGS[args.config])
+        result["config"]["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
+
+    if tr.rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,153 @@
+/*
+ * wun.h -- C ABI of the MI355X-native Wave-U-Net hot path (libwun.so).
+ *
+ * Drop-in boundary for the reference's separator "plugin" surface
+ *   UnetAudioSeparator(model_config)                 /root/reference/Models/UnetAudioSeparator.py:15-32
+ *   .get_padding(shape)                              /root/reference/Models/UnetAudioSeparator.py:34-83
+ *   .get_output(input, training, ...)                /root/reference/Models/UnetAudioSeparator.py:85-144
+ * and for one `sess.run([separator_solver, ...])` of the training loop
+ *   loss + tf.gradients + AdamOptimizer.minimize     /root/reference/Training.py:50-63,70-77,103-109
+ *
+ * Plain C types only.  All device buffers are owned by the CALLER (torch / hipMalloc);
+ * the library owns only an opaque, immutable plan (shape tables + a small device-side
+ * descriptor table).  Every call is asynchronous with respect to the hipStream_t passed
+ * (as void*), re-entrant across plans, and returns 0 or a negative wun_status; the
+ * message is available from wun_last_error() (thread-local).  Nothing aborts.
+ *
+ * Tensor layouts at the boundary are the reference's: audio is float32 [B, T, C]
+ * (channel-last, exactly what get_output receives/returns); kernels are TF layout
+ * [K, Cin, Cout]; variables sit in a flat float32 arena in TF creation order
+ * (conv1d, conv1d_1, ... and interp_<i>), each tensor at the offset the plan reports.
+ */
+#ifndef WUN_H
+#define WUN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum wun_status {
+    WUN_OK = 0,
+    WUN_ERR_INVALID = -1,      /* bad argument / impossible shape (reference: assert)        */
+    WUN_ERR_UNSUPPORTED = -2,  /* reference: NotImplementedError                             */
+    WUN_ERR_HIP = -3,          /* a HIP runtime call failed                                   */
+    WUN_ERR_NOMEM = -4
+} wun_status;
+
+/* The model_config keys UnetAudioSeparator.__init__ reads (UnetAudioSeparator.py:20-32). */
+typedef struct wun_config {
+    int32_t num_layers;
+    int32_t num_initial_filters;
+    int32_t filter_size;
+    int32_t merge_filter_size;
+    int32_t input_filter_size;
+    int32_t output_filter_size;
+    int32_t upsampling;         /* 0 = "linear", 1 = "learned"                                */
+    int32_t output_type;        /* 0 = "direct", 1 = "difference"                             */
+    int32_t context;            /* 0 = same padding, 1 = valid convolutions with context      */
+    int32_t num_sources;        /* len(source_names)                                          */
+    int32_t num_channels;       /* 1 if mono_downmix else 2                                   */
+    int32_t output_activation;  /* 0 = "tanh", 1 = "linear"                                   */
+} wun_config;
+
+typedef struct wun_plan wun_plan;
+
+typedef struct wun_plan_info {
+    int64_t batch;
+    int64_t input_frames;       /* Tin                                                       */
+    int64_t output_frames;      /* Tout                                                      */
+    int64_t num_params;         /* trainable scalars (sum of tensor sizes, no padding)       */
+    int64_t arena_floats;       /* size of the param / grad / m / v arenas (with padding)    */
+    int64_t workspace_floats;   /* activation + gradient + scratch workspace                 */
+    int64_t num_tensors;        /* number of TF variables                                    */
+    int64_t num_outputs;        /* == num_sources                                            */
+    double  fwd_flops;          /* algorithmic conv FLOPs / step as executed (dead work skipped) */
+    double  bwd_flops;
+    double  fwd_flops_dense;    /* the reference graph's FLOPs (no dead-work skipping)       */
+} wun_plan_info;
+
+typedef struct wun_tensor_info {
+    char    name[64];           /* TF variable name, e.g. "separator/conv1d_3/kernel"        */
+    int64_t offset;             /* float offset into the arenas                              */
+    int32_t ndim;
+    int64_t shape[4];
+} wun_tensor_info;
+
+/* UnetAudioSeparator.get_padding (UnetAudioSeparator.py:34-83): smallest valid
+ * (input_frames, output_frames) whose output covers desired_frames.  Pure host integer work. */
+int wun_get_padding(const wun_config* cfg, int64_t desired_frames,
+                    int64_t* input_frames, int64_t* output_frames);
+
+/* Build the static plan for (config, batch, input_frames): the equivalent of the reference
+ * building its TF graph once (Training.py:47).  Fails with WUN_ERR_INVALID where the
+ * reference's asserts would (UnetAudioSeparator.py:55,121; Utils.py:117). */
+int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t input_frames, wun_plan** out);
+void wun_plan_destroy(wun_plan* plan);
+int wun_plan_query(const wun_plan* plan, wun_plan_info* info);
+int wun_plan_tensor(const wun_plan* plan, int64_t index, wun_tensor_info* info);
+
+/* get_output (UnetAudioSeparator.py:85-144).
+ *   params   : device, arena_floats
+ *   mix_btc  : device, [B, Tin, C]
+ *   workspace: device, workspace_floats (intermediates are kept for wun_loss_backward)
+ *   outputs  : device, [S, B, Tout, C] -- source s in source_names order
+ *   training : 0 => AudioClip active (Utils.py:82-92) */
+int wun_forward(const wun_plan* plan, const float* params, const float* mix_btc,
+                float* workspace, float* outputs, int training, void* stream);
+
+/* Loss (Training.py:50-63) + full backward of the graph (the tf.gradients implied by
+ * Training.py:77).  Must follow wun_forward(training=1) on the same workspace/outputs.
+ *   targets  : device, [S, B, Tout, C]
+ *   grads    : device, arena_floats (overwritten)
+ *   loss     : device, 1 float */
+int wun_loss_backward(const wun_plan* plan, const float* params, const float* mix_btc,
+                      float* workspace, const float* outputs, const float* targets,
+                      float* grads, float* loss, void* stream);
+
+/* tf.train.AdamOptimizer update (Training.py:77), TF rule:
+ *   lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v; theta -= lr_t*m/(sqrt(v)+eps); g := grad_scale*grad
+ * step is 1-based.  grad_scale = 1/world_size after a sum all-reduce. */
+int wun_adam_step(const wun_plan* plan, float* params, const float* grads, float* m, float* v,
+                  int64_t step, float lr, float beta1, float beta2, float eps, float grad_scale,
+                  void* stream);
+
+/* ---- single operators (used by the parity tests and for per-kernel profiling) ---------- */
+
+/* y[b][co][q] = act(bias[co] + sum_{k,ci} w[k][ci][co] * x[b][ci][q*stride + k - pad_left]),
+ * x zero outside [0, t_in).  NCW float32, w in TF layout [K, Cin, Cout].
+ * stride in {1, 2}; t_out is given by the caller.  lrelu: 0/1 (alpha = 0.2). */
+int wun_op_conv1d(const float* x, const float* w, const float* bias, float* y,
+                  int batch, int cin, int cout, int k, int t_in, int t_out,
+                  int stride, int pad_left, int lrelu, void* stream);
+
+/* dw[k][ci][co] = sum_{b,q} x[b][ci][q*stride + k - pad_left] * dz[b][co][q]; db[co] = sum dz.
+ * scratch: device floats, at least wun_op_conv1d_wgrad_scratch(...) of them. */
+int64_t wun_op_conv1d_wgrad_scratch(int batch, int cin, int cout, int k, int t_out);
+int wun_op_conv1d_wgrad(const float* x, const float* dz, float* dw, float* db, float* scratch,
+                        int batch, int cin, int cout, int k, int t_in, int t_out,
+                        int stride, int pad_left, void* stream);
+
+/* dx[b][ci][t] = sum_{k,co} w[k][ci][co] * dz[b][co][(t + pad_left - k)/stride] (when divisible
+ * and in range).  wt_scratch: device floats, >= 2*k*cin*cout. */
+int wun_op_conv1d_dgrad(const float* dz, const float* w, float* dx, float* wt_scratch,
+                        int batch, int cin, int cout, int k, int t_in, int t_out,
+                        int stride, int pad_left, void* stream);
+
+/* Lane layout probe of v_mfma_f32_16x16x4_f32: d[16][16] = a[16][4] * b[4][16] (row-major). */
+int wun_op_mfma_probe(const float* a, const float* b, float* d, void* stream);
+
+/* Per-kernel timing with HIP events recorded on the launch stream around every heavy launch
+ * between begin and end; end() synchronises and writes a JSON summary
+ * {"kernels":[{"name","launches","ms","flops"}]} (used by bench.py for the roofline line). */
+int wun_profile_begin(void);
+int wun_profile_end(char* json_out, int64_t capacity);
+
+const char* wun_last_error(void);
+const char* wun_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WUN_H */

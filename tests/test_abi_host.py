@@ -1,0 +1,125 @@
+"""CPU-only checks of the C ABI: the library loads, exports every symbol include/wun.h
+declares, and its host-side integer logic (get_padding, variable arena, plan shapes)
+agrees with the reference-pinned oracle.  No compute calls (no GPU here)."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import shapes
+from oracle.golden_params import GOLDEN_CASES
+
+import wave_u_net_amd as wun
+from wave_u_net_amd import _lib
+from wave_u_net_amd.separator import UnetAudioSeparator, _wun_config
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return _lib.load()
+
+
+def test_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "wun.h")).read()
+    declared = set(re.findall(r"\b(wun_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations found"
+    assert declared == set(_lib.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.wun_version().decode().startswith("wun")
+
+
+def _oracle_cfg(**kw):
+    return shapes.finalize_config(dict(shapes.BASE_MODEL_CONFIG, **kw))
+
+
+def test_get_padding_through_abi_matches_reference(golden_dir):
+    cases = json.load(open(os.path.join(golden_dir, "get_padding.json")))
+    for c in cases:
+        cfg = wun.get_config("baseline", num_layers=c["num_layers"], filter_size=c["filter_size"],
+                             merge_filter_size=c["merge_filter_size"],
+                             input_filter_size=c["input_filter_size"],
+                             output_filter_size=c["output_filter_size"], context=c["context"],
+                             mono_downmix=c["mono_downmix"])
+        sep = UnetAudioSeparator(cfg)
+        i, o = sep.get_padding(np.array([16, c["desired"], 0]))
+        assert list(i) == c["input_shape"] and list(o) == c["output_shape"], c
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN_CASES))
+def test_plan_tables_match_oracle(name, lib):
+    case = GOLDEN_CASES[name]
+    ocfg = _oracle_cfg(**case["cfg"])
+    cfg = wun.get_config("baseline", **case["cfg"])
+    sep = UnetAudioSeparator(cfg)
+    i, o = shapes.get_padding(ocfg, [case["batch"], case["frames"], 0])
+    plan = sep._plan(case["batch"], i[1])
+    assert plan.info.input_frames == i[1]
+    lt = shapes.layer_table(ocfg, i[1])
+    assert plan.info.output_frames == lt["t_out"]
+    if ocfg["context"]:
+        assert plan.info.output_frames == o[1]
+    want = shapes.variable_table(ocfg)
+    got = [(n, list(s)) for n, _, s in plan.tensors]
+    assert got == [(n, list(s)) for n, s in want]
+    # arena is the TF-order concatenation with no padding
+    off = 0
+    for (n, o_, s) in plan.tensors:
+        assert o_ == off, n
+        off += int(np.prod(s))
+    assert plan.info.arena_floats == off == plan.info.num_params == shapes.num_params(ocfg)
+    assert plan.info.workspace_floats > 0
+    assert plan.info.fwd_flops <= plan.info.fwd_flops_dense + 1e-6 * plan.info.fwd_flops_dense \
+        or not ocfg["context"]
+
+
+def test_m1_sizes_and_flops():
+    sep = UnetAudioSeparator(wun.get_config("m1_context"))
+    plan = sep._plan(16, 147443)
+    assert plan.info.output_frames == 16389
+    assert plan.info.num_params == 10263028
+    per_ex = plan.info.fwd_flops_dense / 16
+    assert abs(per_ex - 22.79e9) / 22.79e9 < 0.01          # 22.79 GFLOP / example
+    # dead-work skipping removes ~39 % of the forward FLOPs
+    assert 0.55 < plan.info.fwd_flops / plan.info.fwd_flops_dense < 0.68
+    sep1 = UnetAudioSeparator(wun.get_config("baseline"))
+    plan1 = sep1._plan(16, 16384)
+    assert abs(plan1.info.fwd_flops_dense / 16 - 4.887e9) / 4.887e9 < 0.01
+    assert plan1.info.fwd_flops == plan1.info.fwd_flops_dense
+
+
+def test_error_behaviour_matches_reference():
+    # same-padding input not divisible by 2^L trips the reference assert (UnetAudioSeparator.py:121)
+    sep = UnetAudioSeparator(wun.get_config("baseline", num_layers=3))
+    with pytest.raises(ValueError):
+        sep._plan(1, 100)
+    # get_padding assert x >= 2 (UnetAudioSeparator.py:55) can not trip for desired >= 1; but an
+    # input that is too short for the valid convs must fail
+    sepc = UnetAudioSeparator(wun.get_config("m1_context"))
+    with pytest.raises(ValueError):
+        sepc._plan(1, 1000)
+    with pytest.raises(NotImplementedError):                 # UnetAudioSeparator.py:136
+        UnetAudioSeparator(wun.get_config("baseline", output_activation="relu"))
+    with pytest.raises(NotImplementedError):                 # UnetAudioSeparator.py:144
+        UnetAudioSeparator(wun.get_config("baseline", output_type="sum"))
+
+
+def test_named_configs_present():
+    for n in ["baseline", "baseline_diff", "baseline_context", "baseline_stereo", "full", "full_44KHz",
+              "baseline_context_smallfilter_deep", "full_multi_instrument", "baseline_comparison"]:
+        cfg = wun.get_config(n)
+        assert cfg["num_sources"] == len(cfg["source_names"])
+    assert wun.get_config("full_multi_instrument")["source_names"] == ["bass", "drums", "other", "vocals"]
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "wave-u-net_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src, fn

@@ -1,0 +1,352 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI
+(libwun.so via wave_u_net_amd), against the oracle on the same seeded inputs and against
+the committed goldens generated from the reference's own graph code.
+
+Tolerances (fp32 path, stated per BASELINE.json north_star "within a stated fp32
+tolerance"): single ops 1e-4 * max|ref|; network outputs 2e-4 absolute (outputs are O(1));
+loss 1e-5 relative; gradients 2e-3 * max|grad tensor| + 1e-7 (fp32 reductions over up to
+2.4M positions vs float64 oracle)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import shapes, waveunet_torch as wt
+from oracle.golden_params import GOLDEN_CASES, golden_params
+
+pytestmark = pytest.mark.gpu
+
+import wave_u_net_amd as wun                      # noqa: E402
+from wave_u_net_amd import _lib                   # noqa: E402
+from wave_u_net_amd.separator import UnetAudioSeparator   # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return _lib.load()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _cuda(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).cuda()
+
+
+def test_native_library_is_loaded(lib):
+    maps = open("/proc/self/maps").read()
+    assert "libwun.so" in maps
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+
+
+def test_mfma_lane_layout(lib):
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((16, 4)).astype(np.float32)      # asymmetric operands catch transposes
+    b = rng.standard_normal((4, 16)).astype(np.float32)
+    da, db = _cuda(a), _cuda(b)
+    dd = torch.zeros(16, 16, device="cuda")
+    _lib.check(lib.wun_op_mfma_probe(da.data_ptr(), db.data_ptr(), dd.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    ref = a.astype(np.float64) @ b.astype(np.float64)
+    assert np.abs(dd.cpu().numpy() - ref).max() < 1e-5
+
+
+CONV_CASES = [
+    # (B, Cin, Cout, K, T_in, stride, pad_left, same)
+    (2, 24, 48, 15, 700, 1, 0, False),
+    (2, 24, 48, 15, 701, 2, 0, False),
+    (1, 48, 72, 15, 1100, 2, 0, False),
+    (2, 1, 24, 15, 1000, 1, 0, False),
+    (2, 1, 24, 15, 1001, 2, 0, False),
+    (2, 2, 24, 15, 600, 2, 0, False),
+    (1, 72, 24, 5, 500, 1, 0, False),
+    (2, 40, 24, 5, 300, 1, 2, True),
+    (2, 24, 48, 15, 512, 1, 7, True),
+    (3, 288, 312, 15, 23, 1, 0, False),
+    (2, 264, 288, 15, 59, 2, 0, False),
+    (2, 600, 288, 5, 17, 1, 0, False),
+    (2, 13, 7, 4, 90, 1, 1, True),
+    (2, 13, 7, 7, 91, 2, 0, False),
+    (1, 6, 5, 3, 40, 1, 0, False),
+    (2, 120, 144, 15, 200, 1, 0, False),
+    (2, 168, 176, 15, 100, 1, 0, False),
+    (1, 26, 2, 1, 333, 1, 0, False),
+    (1, 96, 120, 15, 260, 2, 0, False),
+]
+
+
+def _conv_ref(x, w, bias, stride, pad_left, t_out, lrelu):
+    K = w.shape[0]
+    xx = torch.as_tensor(x, dtype=torch.float64)
+    need = (t_out - 1) * stride + K - pad_left
+    pad_r = max(0, need - xx.shape[2])
+    xx = F.pad(xx, (pad_left, pad_r))
+    y = F.conv1d(xx, torch.as_tensor(w, dtype=torch.float64).permute(2, 1, 0),
+                 torch.as_tensor(bias, dtype=torch.float64), stride=stride)[:, :, :t_out]
+    if lrelu:
+        y = torch.maximum(0.2 * y, y)
+    return y.numpy()
+
+
+def _t_out(T, K, stride, same):
+    if same:
+        return T
+    return (T - K) // stride + 1
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
+def test_op_conv1d_forward(lib, case):
+    B, Cin, Cout, K, T, stride, pad, same = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    x = rng.uniform(-1, 1, (B, Cin, T)).astype(np.float32)
+    w = (rng.uniform(-1, 1, (K, Cin, Cout)) / np.sqrt(K * Cin)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, Cout).astype(np.float32)
+    t_out = _t_out(T, K, stride, same)
+    y = torch.full((B, Cout, t_out), float("nan"), device="cuda")
+    dx, dw, db_ = _cuda(x), _cuda(w), _cuda(b)
+    _lib.check(lib.wun_op_conv1d(dx.data_ptr(), dw.data_ptr(), db_.data_ptr(), y.data_ptr(), B, Cin, Cout,
+                                 K, T, t_out, stride, pad, 1, _stream()))
+    torch.cuda.synchronize()
+    ref = _conv_ref(x, w, b, stride, pad, t_out, True)
+    got = y.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
+def test_op_conv1d_wgrad_and_dgrad(lib, case):
+    B, Cin, Cout, K, T, stride, pad, same = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31) + 1)
+    x = rng.uniform(-1, 1, (B, Cin, T)).astype(np.float32)
+    w = (rng.uniform(-1, 1, (K, Cin, Cout)) / np.sqrt(K * Cin)).astype(np.float32)
+    t_out = _t_out(T, K, stride, same)
+    dz = rng.uniform(-1, 1, (B, Cout, t_out)).astype(np.float32)
+    # float64 reference through autograd
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wtn = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    need = (t_out - 1) * stride + K - pad
+    xp = F.pad(xt, (pad, max(0, need - T)))
+    y = F.conv1d(xp, wtn.permute(2, 1, 0), None, stride=stride)[:, :, :t_out]
+    (y * torch.tensor(dz, dtype=torch.float64)).sum().backward()
+    ref_dw, ref_dx = wtn.grad.numpy(), xt.grad.numpy()
+    ref_db = dz.astype(np.float64).sum(axis=(0, 2))
+
+    dxg, dwg, dzg = _cuda(x), _cuda(w), _cuda(dz)
+    n_scr = lib.wun_op_conv1d_wgrad_scratch(B, Cin, Cout, K, t_out)
+    scr = torch.empty(int(n_scr), device="cuda")
+    gdw = torch.full((K, Cin, Cout), float("nan"), device="cuda")
+    gdb = torch.full((Cout,), float("nan"), device="cuda")
+    _lib.check(lib.wun_op_conv1d_wgrad(dxg.data_ptr(), dzg.data_ptr(), gdw.data_ptr(), gdb.data_ptr(),
+                                       scr.data_ptr(), B, Cin, Cout, K, T, t_out, stride, pad, _stream()))
+    torch.cuda.synchronize()
+    assert np.abs(gdw.cpu().numpy() - ref_dw).max() <= 1e-4 * max(1.0, np.abs(ref_dw).max())
+    assert np.abs(gdb.cpu().numpy() - ref_db).max() <= 1e-4 * max(1.0, np.abs(ref_db).max())
+
+    if stride == 2 and pad != 0:
+        return
+    wts = torch.empty(2 * K * Cin * Cout, device="cuda")
+    gdx = torch.full((B, Cin, T), float("nan"), device="cuda")
+    _lib.check(lib.wun_op_conv1d_dgrad(dzg.data_ptr(), dwg.data_ptr(), gdx.data_ptr(), wts.data_ptr(), B, Cin,
+                                       Cout, K, T, t_out, stride, pad, _stream()))
+    torch.cuda.synchronize()
+    got = gdx.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref_dx).max() <= 1e-4 * max(1.0, np.abs(ref_dx).max())
+
+
+def _ocfg(case):
+    return shapes.finalize_config(dict(shapes.BASE_MODEL_CONFIG, **case["cfg"]))
+
+
+def _make_sep(case, params):
+    cfg = wun.get_config("baseline", **case["cfg"])
+    sep = UnetAudioSeparator(cfg, device="cuda:0")
+    return sep, cfg
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN_CASES))
+def test_forward_matches_reference_goldens(lib, name, golden_dir):
+    """HIP get_output vs outputs of the reference's own graph code (tests/golden)."""
+    case = GOLDEN_CASES[name]
+    ocfg = _ocfg(case)
+    g = np.load(os.path.join(golden_dir, "fwd_%s.npz" % name))
+    params = golden_params(ocfg, case["seed"])
+    sep, cfg = _make_sep(case, params)
+    mix = torch.from_numpy(g["mix"]).cuda()
+    sep._plan(mix.shape[0], mix.shape[1])
+    sep._active = sep._plans[(mix.shape[0], mix.shape[1])]
+    sep.load_variables(params)
+    outs = sep.get_output(mix, case["training"])
+    torch.cuda.synchronize()
+    assert list(outs.keys()) == ocfg["source_names"]
+    for n in ocfg["source_names"]:
+        got = outs[n].cpu().numpy()
+        ref = g["out_" + n]
+        assert got.shape == ref.shape
+        assert np.isfinite(got).all(), n
+        assert np.abs(got - ref).max() <= 2e-4, (n, np.abs(got - ref).max())
+
+
+STEP_CASES = ["baseline_small", "baseline_diff_small", "baseline_context_small", "baseline_stereo_small",
+              "full_small", "full_multi_small", "learned_same_small", "odd_filters_small",
+              "odd_filters_same_small"]
+
+
+def _grad_check(sep, tp, ograds, tol=2e-3):
+    g = sep.gradients()
+    worst = []
+    for (n, _), og in zip(tp, ograds):
+        got = g[n].cpu().double()
+        scale = max(og.abs().max().item(), 1e-30)
+        err = (got - og).abs().max().item()
+        worst.append((err / scale, n, err, scale))
+        assert torch.isfinite(got).all(), n
+    worst.sort(reverse=True)
+    bad = [w for w in worst if w[2] > tol * w[3] + 1e-7]
+    assert not bad, bad[:5]
+
+
+@pytest.mark.parametrize("name", STEP_CASES)
+def test_train_step_matches_oracle(lib, name):
+    """loss, every variable's gradient and one TF-Adam update vs the float64 oracle."""
+    case = GOLDEN_CASES[name]
+    ocfg = _ocfg(case)
+    params = golden_params(ocfg, case["seed"])
+    sep, cfg = _make_sep(case, params)
+    B = 3
+    i, o = shapes.get_padding(ocfg, [B, case["frames"], 0])
+    mix, targets = wt.synthetic_batch(ocfg, B, i[1], o[1], seed=case["seed"] + 100)
+    sep._plan(B, i[1]); sep._active = sep._plans[(B, i[1])]
+    sep.load_variables(params)
+    outs = sep.get_output(torch.from_numpy(mix).cuda(), True)
+    loss = sep.loss_and_gradients({k: torch.from_numpy(v) for k, v in targets.items()})
+    torch.cuda.synchronize()
+
+    tp = wt.params_to_torch(params, torch.float64, requires_grad=True)
+    tmix = torch.tensor(mix, dtype=torch.float64)
+    ttg = {k: torch.tensor(v, dtype=torch.float64) for k, v in targets.items()}
+    oloss, ograds = wt.train_step(ocfg, tp, tmix, ttg)
+    oouts = wt.get_output(ocfg, tp, tmix, True)
+    for n in ocfg["source_names"]:
+        assert (outs[n].cpu().double() - oouts[n].detach()).abs().max().item() <= 2e-4, n
+    assert abs(loss.item() - oloss.item()) <= 1e-5 * max(abs(oloss.item()), 1e-3)
+    _grad_check(sep, tp, ograds)
+
+    # one TF-rule Adam update: the kernel vs the oracle's tf_adam_step fed with the SAME (GPU)
+    # gradients, so this isolates the optimizer arithmetic from gradient round-off
+    g = sep.gradients()
+    gp = [g[n].cpu().double() for n, _ in tp]
+    pp = [p.detach().clone() for _, p in tp]
+    m = [torch.zeros_like(p) for p in pp]
+    v = [torch.zeros_like(p) for p in pp]
+    wt.tf_adam_step(pp, gp, m, v, 1, 1e-3)
+    sep.adam_step(1e-3)
+    torch.cuda.synchronize()
+    var = sep.variables()
+    for (n, _), p in zip(tp, pp):
+        assert (var[n].cpu().double() - p).abs().max().item() <= 2e-6, n
+    # second step exercises the moment buffers
+    wt.tf_adam_step(pp, gp, m, v, 2, 1e-3)
+    sep.adam_step(1e-3)
+    torch.cuda.synchronize()
+    var = sep.variables()
+    for (n, _), p in zip(tp, pp):
+        assert (var[n].cpu().double() - p).abs().max().item() <= 4e-6, n
+
+
+def test_full_size_m1_context_step_vs_oracle(lib):
+    """BASELINE.json configs[1] architecture at B=2 (the oracle's fp32 backward of one
+    147443-sample excerpt takes seconds): loss + all 54 gradients."""
+    ocfg = shapes.finalize_config(dict(shapes.BASE_MODEL_CONFIG, context=True))
+    params = golden_params(ocfg, 77)
+    sep = UnetAudioSeparator(wun.get_config("m1_context"), device="cuda:0")
+    B = 2
+    i, o = shapes.get_padding(ocfg, [B, 16384, 0])
+    mix, targets = wt.synthetic_batch(ocfg, B, i[1], o[1], seed=78)
+    sep._plan(B, i[1]); sep._active = sep._plans[(B, i[1])]
+    sep.load_variables(params)
+    outs = sep.get_output(torch.from_numpy(mix).cuda(), True)
+    loss = sep.loss_and_gradients({k: torch.from_numpy(v) for k, v in targets.items()})
+    torch.cuda.synchronize()
+    tp = wt.params_to_torch(params, torch.float32, requires_grad=True)
+    oloss, ograds = wt.train_step(ocfg, tp, torch.from_numpy(mix), {k: torch.from_numpy(v) for k, v in targets.items()})
+    assert abs(loss.item() - oloss.item()) <= 2e-5 * abs(oloss.item())
+    _grad_check(sep, tp, [g.double() for g in ograds], tol=5e-3)
+
+
+def test_full_size_m1_same_step_vs_oracle(lib):
+    """BASELINE.json configs[0]: M1 as shipped (same padding, 16384 samples), B=2."""
+    ocfg = shapes.finalize_config(dict(shapes.BASE_MODEL_CONFIG))
+    params = golden_params(ocfg, 79)
+    sep = UnetAudioSeparator(wun.get_config("baseline"), device="cuda:0")
+    B = 2
+    mix, targets = wt.synthetic_batch(ocfg, B, 16384, 16384, seed=80)
+    sep._plan(B, 16384); sep._active = sep._plans[(B, 16384)]
+    sep.load_variables(params)
+    sep.get_output(torch.from_numpy(mix).cuda(), True)
+    loss = sep.loss_and_gradients({k: torch.from_numpy(v) for k, v in targets.items()})
+    torch.cuda.synchronize()
+    tp = wt.params_to_torch(params, torch.float32, requires_grad=True)
+    oloss, ograds = wt.train_step(ocfg, tp, torch.from_numpy(mix), {k: torch.from_numpy(v) for k, v in targets.items()})
+    assert abs(loss.item() - oloss.item()) <= 2e-5 * abs(oloss.item())
+    _grad_check(sep, tp, [g.double() for g in ograds], tol=5e-3)
+
+
+def test_full_batch_properties_m1_context(lib):
+    """At BASELINE.json's full size (B=16, 147443 -> 16389) the oracle is too slow for a
+    per-element check, so use size-independent properties: (1) determinism -- two runs are
+    bit-identical; (2) batch independence -- excerpt b of a B=16 run equals the same excerpt
+    run alone, bit for bit; (3) the B=16 gradient is the mean of per-excerpt gradients."""
+    ocfg = shapes.finalize_config(dict(shapes.BASE_MODEL_CONFIG, context=True))
+    params = golden_params(ocfg, 81)
+    sep = UnetAudioSeparator(wun.get_config("m1_context"), device="cuda:0")
+    B = 16
+    mix, targets = wt.synthetic_batch(ocfg, B, 147443, 16389, seed=82)
+    dmix = torch.from_numpy(mix).cuda()
+    tg = torch.stack([torch.from_numpy(targets[n]) for n in ocfg["source_names"]]).cuda()
+    sep._plan(B, 147443); sep._active = sep._plans[(B, 147443)]
+    sep.load_variables(params)
+    o1 = torch.stack(list(sep.get_output(dmix, True).values())).clone()
+    l1 = sep.loss_and_gradients(tg).clone()
+    g1 = sep.grads.clone()
+    o2 = torch.stack(list(sep.get_output(dmix, True).values())).clone()
+    l2 = sep.loss_and_gradients(tg).clone()
+    g2 = sep.grads.clone()
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2) and torch.equal(l1, l2) and torch.equal(g1, g2)
+    assert torch.isfinite(g1).all() and torch.isfinite(o1).all()
+    gsum = torch.zeros_like(g1)
+    for b in (0, 7, 15):
+        ob = torch.stack(list(sep.get_output(dmix[b:b + 1], True).values()))
+        assert torch.equal(ob[:, 0], o1[:, b]), b
+    for b in range(B):
+        sep.get_output(dmix[b:b + 1], True)
+        sep.loss_and_gradients(tg[:, b:b + 1])
+        gsum += sep.grads
+    torch.cuda.synchronize()
+    gmean = gsum / B
+    scale = g1.abs().max().item()
+    assert (gmean - g1).abs().max().item() <= 1e-4 * scale
+    # 'training=False' clips only for the linear activation; tanh outputs stay in (-1, 1)
+    assert o1.abs().max().item() < 1.0
+
+
+def test_inference_mode_clip(lib):
+    case = GOLDEN_CASES["linear_act_eval_small"]
+    ocfg = _ocfg(case)
+    params = golden_params(ocfg, case["seed"])
+    sep, cfg = _make_sep(case, params)
+    i, o = shapes.get_padding(ocfg, [2, case["frames"], 0])
+    mix = np.random.default_rng(5).uniform(-3, 3, (2, i[1], 1)).astype(np.float32)
+    sep._plan(2, i[1]); sep._active = sep._plans[(2, i[1])]
+    sep.load_variables(params)
+    ev = sep.get_output(torch.from_numpy(mix).cuda(), False)
+    for n in ocfg["source_names"]:
+        assert ev[n].abs().max().item() <= 1.0
+    tr = sep.get_output(torch.from_numpy(mix).cuda(), True)
+    assert max(tr[n].abs().max().item() for n in ocfg["source_names"]) > 1.0

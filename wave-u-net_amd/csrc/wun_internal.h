@@ -1,0 +1,131 @@
+// Internal: kernel argument blocks + launcher prototypes shared by wun_kernels.hip
+// (device code) and wun_plan.hip (host plan / C ABI).  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+namespace wun {
+
+enum { LOADER_DIRECT = 0, LOADER_DEINT = 1 };
+
+// Epilogue flag bits
+enum { F_LRELU = 1, F_ACCUM = 2 };
+
+// One implicit-GEMM 1-D convolution launch.  The input is a virtual channel-concat of
+// up to two NCW sources, zero outside [0, Tin) (this is how crop+concat, 'same' zero
+// padding and the halo of valid convolutions are expressed without copies).
+//   DIRECT: out[b][n][q] = epi( sum_{j<J, c} W[j][c][n] * in[b][c][q + j - shift] )
+//   DEINT : out[b][n][q] = epi( sum_{k<KW,c} W[k][c][n] * in[b][c][2q + k - shift] )
+// Outputs n < N0 go to dst0, the rest to dst1 (dgrad of a concat).  Output element q is
+// stored at dst[b*obs + n*opitch + ooff + q*ostride]; msk (same geometry as dst) applies
+// the LeakyReLU derivative of the forward activation stored there; dec receives a
+// compact copy of the even q (the [:, ::2, :] decimation) of dst0.
+struct ConvArgs {
+    const float* src0; const float* src1;
+    long long bs0, bs1;
+    int pitch0, pitch1;
+    int off0, off1;
+    int C0, C1;
+    int Tin;
+    int shift;
+    const float* W;
+    const float* bias;
+    int KW;          // taps (DIRECT: J = KW; DEINT: J = ceil(KW/2))
+    int N;           // output channels
+    int N0;          // split point between dst0 / dst1
+    float* dst0; float* dst1;
+    long long obs0, obs1;
+    int opitch0, opitch1;
+    int ooff0, ooff1;
+    const float* msk0; const float* msk1;
+    int ostride;
+    int Tout;
+    float* dec; long long decbs; int decpitch;
+    int flags;
+    int B;
+    int loader;
+};
+
+// Weight/bias gradient launch:  P[split][ (k*C + c)*N + n ] and bias row P[split][KW*C*N + n]
+//   = sum over this split's (b, q-tile) units of in[b][c][q*SI + k - shift] * dz[b][n][q]
+struct WgradArgs {
+    const float* src0; const float* src1;
+    long long bs0, bs1;
+    int pitch0, pitch1;
+    int off0, off1;
+    int C0, C1;
+    int Tin;
+    int shift;
+    int KW;
+    int loader;      // DIRECT (SI = 1) / DEINT (SI = 2)
+    const float* dz; long long dzbs; int dzpitch; int N; int Tq;
+    float* out; long long split_stride;
+    int nsplit; int units_per_split; int nQT; int B;
+};
+
+struct UpsampleArgs {
+    const float* x; long long xbs; int xpitch; int n;     // [B][C][n]
+    float* y; long long ybs; int ypitch; int tup;          // [B][C][tup]
+    const float* w;                                        // interp weights [C] or null (linear)
+    int C; int B; int context;
+};
+
+struct UpsampleBwdArgs {
+    const float* dy; long long ybs; int ypitch; int tup;   // gradient wrt upsampled tensor
+    const float* x; long long xbs; int xpitch; int n;      // forward input (post-activation)
+    float* dz;                                             // out: dL/d(pre-activation of x), geometry of x
+    const float* w; float* dw;                             // interp weights / their gradient (or null)
+    int C; int B; int context;
+};
+
+struct HeadArgs {
+    const float* mix_ncw; long long mbs; int mpitch; int moff_feat; int moff_diff; // crop offsets
+    const float* feat; long long fbs; int fpitch;          // last up-conv output [B][F][Tfeat]
+    const float* Wh;                                       // head params: per source {kernel [Ko][C+F][C], bias [C]}
+    int C, F, S, Sh, Ko, padl;
+    int Tfeat, Tout, B;
+    int tanh_act, difference, training;
+    float* out;                                            // [S][B][Tout][C]
+    // backward only
+    const float* tgt;                                      // [S][B][Tout][C]
+    float* dpre; long long dps; long long dpbs; int dppitch; // [Sh][B][C][ToutP]
+    float* dzfeat;                                         // geometry of feat
+    float* loss_partial;                                   // [gridDim.x]
+    float gscale;                                          // 2 / (S*B*Tout*C)
+};
+
+struct WtDesc {      // dst[j][n][c] = src[k_last - j*k_step][c][n]
+    long long src_off;   // into params
+    long long dst_off;   // into workspace
+    int J, C, N, k_last, k_step;
+};
+
+// ---- launchers (wun_kernels.hip) ---------------------------------------------------
+size_t conv_lds_bytes(const ConvArgs& a, int variant);
+int  conv_pick_variant(const ConvArgs& a);
+hipError_t launch_conv(const ConvArgs& a, hipStream_t s);
+double conv_flops(const ConvArgs& a);        // useful FLOPs (2*MACs) of the launch
+
+int  wgrad_pick_nsplit(const WgradArgs& a);
+hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s);
+hipError_t launch_reduce(const float* partial, long long stride, int nsplit, float* out,
+                         long long n, hipStream_t s);
+hipError_t launch_upsample(const UpsampleArgs& a, hipStream_t s);
+hipError_t launch_upsample_bwd(const UpsampleBwdArgs& a, hipStream_t s);
+hipError_t launch_head_fwd_off(const HeadArgs& a, const long long* hoff, hipStream_t s);
+int head_bwd_blocks(const HeadArgs& a);
+hipError_t launch_head_bwd_off(const HeadArgs& a, const long long* hoff, hipStream_t s);
+hipError_t launch_loss_finish(const float* partial, int n, float scale, float* loss, hipStream_t s);
+hipError_t launch_btc_to_ncw(const float* src, float* dst, int B, int T, int C, int pitch,
+                             hipStream_t s);
+hipError_t launch_make_wt(const float* params, float* ws, const WtDesc* dev_descs, int ndesc,
+                          int max_elems, hipStream_t s);
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr_t,
+                       float b1, float b2, float eps, float gscale, hipStream_t s);
+hipError_t launch_fill(float* p, long long n, float val, hipStream_t s);
+hipError_t launch_mfma_probe(const float* a, const float* b, float* d, hipStream_t s);
+void prof_begin();
+std::string prof_end();
+
+}  // namespace wun

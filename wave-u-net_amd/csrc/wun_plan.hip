@@ -1,0 +1,792 @@
+// Host side of libwun.so: static plan (the equivalent of the reference building its TF
+// graph once, /root/reference/Training.py:47) and the C ABI declared in include/wun.h.
+#include "../../include/wun.h"
+#include "wun_internal.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace wun;
+
+namespace wun {
+hipError_t launch_make_wt_one(const float* src, float* dst, WtDesc d, hipStream_t s);
+}
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess)                                                                 \
+            return fail(WUN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));      \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------
+// shapes (UnetAudioSeparator.py:34-83, Utils.py:104-123)
+// ---------------------------------------------------------------------------------------
+static int check_config(const wun_config* c) {
+    if (!c) return fail(WUN_ERR_INVALID, "config is null");
+    if (c->num_layers < 1 || c->num_layers > 24) return fail(WUN_ERR_INVALID, "num_layers out of range");
+    if (c->num_initial_filters < 1) return fail(WUN_ERR_INVALID, "num_initial_filters < 1");
+    if (c->filter_size < 1 || c->merge_filter_size < 1 || c->output_filter_size < 1 || c->input_filter_size < 1)
+        return fail(WUN_ERR_INVALID, "filter sizes must be >= 1");
+    if (c->upsampling != 0 && c->upsampling != 1) return fail(WUN_ERR_UNSUPPORTED, "upsampling must be linear|learned");
+    if (c->output_type != 0 && c->output_type != 1) return fail(WUN_ERR_UNSUPPORTED, "output_type must be direct|difference");
+    if (c->output_activation != 0 && c->output_activation != 1)
+        return fail(WUN_ERR_UNSUPPORTED, "output_activation must be tanh|linear");   // UnetAudioSeparator.py:136
+    if (c->num_channels != 1 && c->num_channels != 2) return fail(WUN_ERR_INVALID, "num_channels must be 1 or 2");
+    if (c->num_sources < 1 || c->num_sources > 4) return fail(WUN_ERR_UNSUPPORTED, "num_sources must be 1..4");
+    if (c->output_type == 1 && c->num_sources < 2) return fail(WUN_ERR_INVALID, "difference output needs >= 2 sources");
+    return WUN_OK;
+}
+
+extern "C" int wun_get_padding(const wun_config* cfg, int64_t desired, int64_t* in_frames, int64_t* out_frames) {
+    int rc = check_config(cfg);
+    if (rc) return rc;
+    if (!in_frames || !out_frames) return fail(WUN_ERR_INVALID, "null output pointer");
+    if (!cfg->context) { *in_frames = desired; *out_frames = desired; return WUN_OK; }   // :83
+    double rem = (double)desired;                       // :43
+    rem = rem - cfg->output_filter_size + 1;            // :46
+    for (int i = 0; i < cfg->num_layers; ++i) {         // :49-51
+        rem = rem + cfg->merge_filter_size - 1;
+        rem = (rem + 1.0) / 2.0;
+    }
+    const int64_t x = (int64_t)std::ceil(rem);          // :54
+    if (x < 2) return fail(WUN_ERR_INVALID, "get_padding: bottleneck feature map < 2 (reference assert)");
+    int64_t out = x, inp = x + cfg->filter_size - 1;    // :58-62
+    for (int i = 0; i < cfg->num_layers; ++i) {         // :65-73
+        out = 2 * out - 1;
+        out = out - cfg->merge_filter_size + 1;
+        inp = 2 * inp - 1;
+        inp += (i < cfg->num_layers - 1 ? cfg->filter_size : cfg->input_filter_size) - 1;
+    }
+    out = out - cfg->output_filter_size + 1;            // :76
+    *in_frames = inp;
+    *out_frames = out;
+    return WUN_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------------------
+struct Buf { long long off = -1; int C = 0; int T = 0; int pitch = 0; long long bs = 0; };
+struct ConvLayer { long long woff = 0, boff = 0; int KW = 0, Cin = 0, Cout = 0;
+                   long long wt_full = -1, wt_ph[2] = {-1, -1}; int Jp[2] = {0, 0}; };
+struct DownShape { int cin, cout, t_in, t_conv, t_dec, tc, cs; };
+struct UpShape { int c_skip, c_cur, cout, t_cur, t_up, t_conv, crop_start; };
+
+struct wun_plan {
+    wun_config cfg;
+    int B = 0, Tin = 0, Tout = 0;
+    int L = 0, C = 0, S = 0, Sh = 0;
+    bool same = false;
+    std::vector<wun_tensor_info> tensors;
+    long long arena = 0, ws = 0;
+    std::vector<DownShape> dsh;
+    std::vector<UpShape> ush;
+    int t_b_in = 0, t_b = 0, c_b = 0;
+    int t_feat = 0, in_crop_start = 0, mix_diff_off = 0;
+    std::vector<ConvLayer> down, up, head;
+    ConvLayer bott;
+    std::vector<long long> interp;
+    Buf mix_ncw, bott_out, dz_bott;
+    std::vector<Buf> dec, skip, ups, upo, dz_dec, dz_skip, d_ups, dz_upo;
+    long long dpre_off = -1; int dp_pitch = 0;
+    long long partial_off = -1, partial_floats = 0;
+    long long loss_partial_off = -1;
+    std::vector<WtDesc> wt;
+    WtDesc* dev_wt = nullptr;
+    int wt_max = 0;
+    double fwd_flops = 0, bwd_flops = 0, fwd_dense = 0;
+};
+
+static long long bump(long long& cur, long long n) {
+    const long long off = (cur + 63) / 64 * 64;
+    cur = off + n;
+    return off;
+}
+
+static Buf make_buf(long long& cur, int B, int C, int T) {
+    Buf b;
+    b.C = C; b.T = T; b.pitch = (T + 3) / 4 * 4;
+    b.bs = (long long)C * b.pitch;
+    b.off = bump(cur, (long long)B * b.bs);
+    return b;
+}
+
+static void crop_offsets(int from, int to, int& start, int& end) {   // Utils.py:120-121
+    const int diff = from - to;
+    start = diff / 2;
+    end = diff - start;
+}
+
+static void add_tensor(wun_plan* p, const std::string& name, std::vector<int64_t> shape, long long& cur,
+                       long long* off_out) {
+    wun_tensor_info t;
+    memset(&t, 0, sizeof(t));
+    snprintf(t.name, sizeof(t.name), "%s", name.c_str());
+    t.offset = cur;
+    t.ndim = (int)shape.size();
+    long long n = 1;
+    for (size_t i = 0; i < shape.size(); ++i) { t.shape[i] = shape[i]; n *= shape[i]; }
+    *off_out = cur;
+    cur += n;
+    p->tensors.push_back(t);
+}
+
+static void add_conv(wun_plan* p, int& counter, int K, int cin, int cout, long long& cur, ConvLayer* out) {
+    std::string base = counter == 0 ? "separator/conv1d" : "separator/conv1d_" + std::to_string(counter);
+    ++counter;
+    out->KW = K; out->Cin = cin; out->Cout = cout;
+    add_tensor(p, base + "/kernel", {K, cin, cout}, cur, &out->woff);
+    add_tensor(p, base + "/bias", {cout}, cur, &out->boff);
+}
+
+static WgradArgs wgrad_shape_only(int B, int C0, int C1, int KW, int loader, int N, int Tq) {
+    WgradArgs w;
+    memset(&w, 0, sizeof(w));
+    w.B = B; w.C0 = C0; w.C1 = C1; w.KW = KW; w.loader = loader; w.N = N; w.Tq = Tq;
+    return w;
+}
+
+extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t input_frames, wun_plan** out) {
+    int rc = check_config(cfg);
+    if (rc) return rc;
+    if (!out) return fail(WUN_ERR_INVALID, "out is null");
+    if (batch < 1 || input_frames < 1 || input_frames > (1ll << 30)) return fail(WUN_ERR_INVALID, "bad batch / input_frames");
+    wun_plan* p = new (std::nothrow) wun_plan();
+    if (!p) return fail(WUN_ERR_NOMEM, "out of host memory");
+    p->cfg = *cfg;
+    p->B = (int)batch; p->Tin = (int)input_frames;
+    const int L = p->L = cfg->num_layers, F = cfg->num_initial_filters;
+    const int Kd = cfg->filter_size, Ku = cfg->merge_filter_size, Ko = cfg->output_filter_size;
+    const int C = p->C = cfg->num_channels;
+    p->S = cfg->num_sources;
+    p->Sh = cfg->output_type == 0 ? p->S : p->S - 1;
+    const bool same = p->same = !cfg->context;
+
+    // ---- shape walk of get_output (UnetAudioSeparator.py:97-142) ----
+    auto conv_len = [&](int t, int k) { return same ? t : t - k + 1; };
+    p->dsh.resize(L);
+    int t = p->Tin, cin = C;
+    for (int i = 0; i < L; ++i) {
+        DownShape& d = p->dsh[i];
+        d.cin = cin; d.cout = F + F * i; d.t_in = t; d.t_conv = conv_len(t, Kd);
+        if (d.t_conv < 1) { delete p; return fail(WUN_ERR_INVALID, "input too short for the down path"); }
+        d.t_dec = (d.t_conv + 1) / 2;                       // [:, ::2, :]  :100
+        t = d.t_dec; cin = d.cout;
+    }
+    p->c_b = F + F * L; p->t_b_in = t; p->t_b = conv_len(t, Kd);
+    if (p->t_b < 1) { delete p; return fail(WUN_ERR_INVALID, "input too short for the bottleneck conv"); }
+    p->ush.resize(L);
+    t = p->t_b; int ccur = p->c_b;
+    for (int j = 0; j < L; ++j) {
+        UpShape& u = p->ush[j];
+        const DownShape& d = p->dsh[L - 1 - j];
+        u.c_skip = d.cout; u.c_cur = ccur; u.cout = F + F * (L - j - 1);
+        u.t_cur = t; u.t_up = cfg->context ? 2 * t - 1 : 2 * t;      // :115/:117, InterpolationLayer.py:32
+        if (same && d.t_conv != u.t_up) {                             // :121
+            delete p;
+            return fail(WUN_ERR_INVALID, "same-padding input length must be divisible by 2^num_layers (reference assert UnetAudioSeparator.py:121)");
+        }
+        if (d.t_conv < u.t_up) { delete p; return fail(WUN_ERR_INVALID, "crop with negative difference (Utils.py:117)"); }
+        int ce;
+        crop_offsets(d.t_conv, u.t_up, u.crop_start, ce);
+        u.t_conv = conv_len(u.t_up, Ku);
+        if (u.t_conv < 1) { delete p; return fail(WUN_ERR_INVALID, "input too short for the up path"); }
+        t = u.t_conv; ccur = u.cout;
+    }
+    for (int i = 0; i < L; ++i) {
+        p->dsh[i].tc = p->ush[L - 1 - i].t_up;
+        p->dsh[i].cs = p->ush[L - 1 - i].crop_start;
+    }
+    p->t_feat = t;
+    if (p->Tin < p->t_feat) { delete p; return fail(WUN_ERR_INVALID, "crop with negative difference (Utils.py:117)"); }
+    { int ce; crop_offsets(p->Tin, p->t_feat, p->in_crop_start, ce); }     // :127
+    p->Tout = conv_len(p->t_feat, Ko);
+    if (p->Tout < 1) { delete p; return fail(WUN_ERR_INVALID, "input too short for the output layer"); }
+    { int s2, e2; crop_offsets(p->t_feat, p->Tout, s2, e2); p->mix_diff_off = p->in_crop_start + s2; }  // OutputLayer.py:20
+
+    // ---- variable arena in TF creation order ----
+    long long cur = 0;
+    int counter = 0;
+    p->down.resize(L); p->up.resize(L); p->head.resize(p->Sh);
+    for (int i = 0; i < L; ++i) add_conv(p, counter, Kd, p->dsh[i].cin, p->dsh[i].cout, cur, &p->down[i]);
+    add_conv(p, counter, Kd, p->dsh[L - 1].cout, p->c_b, cur, &p->bott);
+    p->interp.assign(L, -1);
+    for (int j = 0; j < L; ++j) {
+        if (cfg->upsampling == 1)
+            add_tensor(p, "separator/interp_" + std::to_string(j), {p->ush[j].c_cur}, cur, &p->interp[j]);
+        add_conv(p, counter, Ku, p->ush[j].c_skip + p->ush[j].c_cur, p->ush[j].cout, cur, &p->up[j]);
+    }
+    for (int s = 0; s < p->Sh; ++s) add_conv(p, counter, Ko, C + F, C, cur, &p->head[s]);
+    p->arena = cur;
+
+    // ---- workspace ----
+    long long w = 0;
+    const int B = p->B;
+    p->mix_ncw = make_buf(w, B, C, p->Tin);
+    p->dec.resize(L); p->skip.resize(L); p->dz_dec.resize(L); p->dz_skip.resize(L);
+    for (int i = 0; i < L; ++i) {
+        p->dec[i] = make_buf(w, B, p->dsh[i].cout, p->dsh[i].t_dec);
+        p->skip[i] = make_buf(w, B, p->dsh[i].cout, p->dsh[i].tc);
+        if (!same) p->dz_dec[i] = make_buf(w, B, p->dsh[i].cout, p->dsh[i].t_dec);
+        p->dz_skip[i] = make_buf(w, B, p->dsh[i].cout, p->dsh[i].tc);
+    }
+    p->bott_out = make_buf(w, B, p->c_b, p->t_b);
+    p->dz_bott = make_buf(w, B, p->c_b, p->t_b);
+    p->ups.resize(L); p->upo.resize(L); p->d_ups.resize(L); p->dz_upo.resize(L);
+    for (int j = 0; j < L; ++j) {
+        p->ups[j] = make_buf(w, B, p->ush[j].c_cur, p->ush[j].t_up);
+        p->d_ups[j] = make_buf(w, B, p->ush[j].c_cur, p->ush[j].t_up);
+        p->upo[j] = make_buf(w, B, p->ush[j].cout, p->ush[j].t_conv);
+        p->dz_upo[j] = make_buf(w, B, p->ush[j].cout, p->ush[j].t_conv);
+    }
+    p->dp_pitch = (p->Tout + 3) / 4 * 4;
+    p->dpre_off = bump(w, (long long)p->Sh * B * C * p->dp_pitch);
+    p->loss_partial_off = bump(w, 1024);
+
+    // ---- transposed / tap-flipped weights for the input-gradient convs ----
+    auto add_wt = [&](const ConvLayer& cl, int J, int k_last, int k_step) -> long long {
+        WtDesc d;
+        d.src_off = cl.woff; d.J = J; d.C = cl.Cin; d.N = cl.Cout; d.k_last = k_last; d.k_step = k_step;
+        d.dst_off = bump(w, (long long)J * cl.Cin * cl.Cout);
+        p->wt.push_back(d);
+        const long long n = (long long)J * cl.Cin * cl.Cout;
+        if (n > p->wt_max) p->wt_max = (int)n;
+        return d.dst_off;
+    };
+    for (int i = 1; i < L; ++i) {
+        ConvLayer& cl = p->down[i];
+        cl.wt_full = add_wt(cl, cl.KW, cl.KW - 1, 1);
+        if (!same) {
+            for (int ph = 0; ph < 2; ++ph) {
+                const int Jp = (cl.KW - ph + 1) / 2;          // taps k = 2j + ph < KW
+                cl.Jp[ph] = Jp;
+                cl.wt_ph[ph] = add_wt(cl, Jp, 2 * (Jp - 1) + ph, 2);
+            }
+        }
+    }
+    p->bott.wt_full = add_wt(p->bott, Kd, Kd - 1, 1);
+    for (int j = 0; j < L; ++j) p->up[j].wt_full = add_wt(p->up[j], Ku, Ku - 1, 1);
+
+    // ---- wgrad partial buffer: max over layers of (total splits) * (kernel + bias floats) ----
+    long long pmax = 0;
+    auto blockf = [](const ConvLayer& cl) { return (long long)cl.KW * cl.Cin * cl.Cout + cl.Cout; };
+    for (int i = 0; i < L; ++i) {
+        const DownShape& d = p->dsh[i];
+        long long ns;
+        if (same) {
+            ns = wgrad_pick_nsplit(wgrad_shape_only(B, d.cin, 0, Kd, LOADER_DIRECT, d.cout, d.t_conv));
+        } else {
+            ns = wgrad_pick_nsplit(wgrad_shape_only(B, d.cin, 0, Kd, LOADER_DEINT, d.cout, d.t_dec)) +
+                 wgrad_pick_nsplit(wgrad_shape_only(B, d.cin, 0, Kd, LOADER_DIRECT, d.cout, d.tc));
+        }
+        pmax = std::max(pmax, ns * blockf(p->down[i]));
+    }
+    pmax = std::max(pmax, (long long)wgrad_pick_nsplit(wgrad_shape_only(B, p->bott.Cin, 0, Kd, LOADER_DIRECT, p->c_b, p->t_b)) * blockf(p->bott));
+    for (int j = 0; j < L; ++j)
+        pmax = std::max(pmax, (long long)wgrad_pick_nsplit(wgrad_shape_only(B, p->ush[j].c_skip, p->ush[j].c_cur, Ku, LOADER_DIRECT, p->ush[j].cout, p->ush[j].t_conv)) * blockf(p->up[j]));
+    if (p->Sh > 0)
+        pmax = std::max(pmax, (long long)wgrad_pick_nsplit(wgrad_shape_only(B, C, F, Ko, LOADER_DIRECT, C, p->Tout)) * blockf(p->head[0]));
+    p->partial_floats = pmax;
+    p->partial_off = bump(w, pmax);
+    p->ws = (w + 63) / 64 * 64;
+
+    // ---- FLOP accounting (2*MAC of the conv contractions) ----
+    auto cf = [&](int K, double ci, double co, double tt) { return 2.0 * K * ci * co * tt * B; };
+    double fwd = 0, dense = 0, bwd = 0;
+    for (int i = 0; i < L; ++i) {
+        const DownShape& d = p->dsh[i];
+        dense += cf(Kd, d.cin, d.cout, d.t_conv);
+        const double live = same ? cf(Kd, d.cin, d.cout, d.t_conv) : cf(Kd, d.cin, d.cout, d.t_dec) + cf(Kd, d.cin, d.cout, d.tc);
+        fwd += live;
+        bwd += live * (i > 0 ? 2.0 : 1.0);
+    }
+    { const double f = cf(Kd, p->bott.Cin, p->c_b, p->t_b); fwd += f; dense += f; bwd += 2 * f; }
+    for (int j = 0; j < L; ++j) {
+        const double f = cf(Ku, p->ush[j].c_skip + p->ush[j].c_cur, p->ush[j].cout, p->ush[j].t_conv);
+        fwd += f; dense += f; bwd += 2 * f;
+    }
+    { const double f = p->Sh * cf(Ko, C + F, C, p->Tout); fwd += f; dense += f; bwd += 2 * f; }
+    p->fwd_flops = fwd; p->bwd_flops = bwd; p->fwd_dense = dense;
+
+    // ---- device-side descriptor table (the only device memory the plan owns) ----
+    if (!p->wt.empty()) {
+        hipError_t e = hipMalloc((void**)&p->dev_wt, p->wt.size() * sizeof(WtDesc));
+        if (e == hipSuccess) e = hipMemcpy(p->dev_wt, p->wt.data(), p->wt.size() * sizeof(WtDesc), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            // no device available (e.g. CPU-only build box): the plan is still usable for queries
+            p->dev_wt = nullptr;
+            (void)hipGetLastError();
+        }
+    }
+    *out = p;
+    return WUN_OK;
+}
+
+extern "C" void wun_plan_destroy(wun_plan* p) {
+    if (!p) return;
+    if (p->dev_wt) (void)hipFree(p->dev_wt);
+    delete p;
+}
+
+extern "C" int wun_plan_query(const wun_plan* p, wun_plan_info* info) {
+    if (!p || !info) return fail(WUN_ERR_INVALID, "null argument");
+    info->batch = p->B; info->input_frames = p->Tin; info->output_frames = p->Tout;
+    long long n = 0;
+    for (const auto& t : p->tensors) { long long k = 1; for (int i = 0; i < t.ndim; ++i) k *= t.shape[i]; n += k; }
+    info->num_params = n; info->arena_floats = p->arena; info->workspace_floats = p->ws;
+    info->num_tensors = (int64_t)p->tensors.size(); info->num_outputs = p->S;
+    info->fwd_flops = p->fwd_flops; info->bwd_flops = p->bwd_flops; info->fwd_flops_dense = p->fwd_dense;
+    return WUN_OK;
+}
+
+extern "C" int wun_plan_tensor(const wun_plan* p, int64_t index, wun_tensor_info* info) {
+    if (!p || !info) return fail(WUN_ERR_INVALID, "null argument");
+    if (index < 0 || index >= (int64_t)p->tensors.size()) return fail(WUN_ERR_INVALID, "tensor index out of range");
+    *info = p->tensors[(size_t)index];
+    return WUN_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// helpers to fill argument blocks
+// ---------------------------------------------------------------------------------------
+static ConvArgs conv_base(const wun_plan* p) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = p->B; a.ostride = 1; a.loader = LOADER_DIRECT;
+    return a;
+}
+static void set_src0(ConvArgs& a, const float* ws, const Buf& b, int off, int C) {
+    a.src0 = ws + b.off; a.bs0 = b.bs; a.pitch0 = b.pitch; a.off0 = off; a.C0 = C;
+}
+static void set_src1(ConvArgs& a, const float* ws, const Buf& b, int off, int C) {
+    a.src1 = ws + b.off; a.bs1 = b.bs; a.pitch1 = b.pitch; a.off1 = off; a.C1 = C;
+}
+static void set_dst0(ConvArgs& a, float* ws, const Buf& b, int off, const Buf* mask) {
+    a.dst0 = ws + b.off; a.obs0 = b.bs; a.opitch0 = b.pitch; a.ooff0 = off;
+    a.msk0 = mask ? ws + mask->off : nullptr;
+}
+static void set_dst1(ConvArgs& a, float* ws, const Buf& b, int off, const Buf* mask) {
+    a.dst1 = ws + b.off; a.obs1 = b.bs; a.opitch1 = b.pitch; a.ooff1 = off;
+    a.msk1 = mask ? ws + mask->off : nullptr;
+}
+static WgradArgs wgrad_base(const wun_plan* p) {
+    WgradArgs w;
+    memset(&w, 0, sizeof(w));
+    w.B = p->B; w.loader = LOADER_DIRECT;
+    return w;
+}
+static void wset_src0(WgradArgs& a, const float* ws, const Buf& b, int off, int C) {
+    a.src0 = ws + b.off; a.bs0 = b.bs; a.pitch0 = b.pitch; a.off0 = off; a.C0 = C;
+}
+static void wset_src1(WgradArgs& a, const float* ws, const Buf& b, int off, int C) {
+    a.src1 = ws + b.off; a.bs1 = b.bs; a.pitch1 = b.pitch; a.off1 = off; a.C1 = C;
+}
+static void wset_dz(WgradArgs& a, const float* base, long long bs, int pitch, int N, int Tq) {
+    a.dz = base; a.dzbs = bs; a.dzpitch = pitch; a.N = N; a.Tq = Tq;
+}
+
+static HeadArgs head_args(const wun_plan* p, const float* params, float* ws, float* outputs, int training) {
+    HeadArgs h;
+    memset(&h, 0, sizeof(h));
+    const int L = p->L;
+    h.mix_ncw = ws + p->mix_ncw.off; h.mbs = p->mix_ncw.bs; h.mpitch = p->mix_ncw.pitch;
+    h.moff_feat = p->in_crop_start; h.moff_diff = p->mix_diff_off;
+    h.feat = ws + p->upo[L - 1].off; h.fbs = p->upo[L - 1].bs; h.fpitch = p->upo[L - 1].pitch;
+    h.Wh = params;
+    h.C = p->C; h.F = p->cfg.num_initial_filters; h.S = p->S; h.Sh = p->Sh; h.Ko = p->cfg.output_filter_size;
+    h.padl = p->same ? (h.Ko - 1) / 2 : 0;
+    h.Tfeat = p->t_feat; h.Tout = p->Tout; h.B = p->B;
+    h.tanh_act = p->cfg.output_activation == 0; h.difference = p->cfg.output_type == 1; h.training = training;
+    h.out = outputs;
+    h.dpre = ws + p->dpre_off; h.dppitch = p->dp_pitch; h.dpbs = (long long)p->C * p->dp_pitch;
+    h.dps = (long long)p->B * h.dpbs;
+    h.dzfeat = ws + p->dz_upo[L - 1].off;
+    h.loss_partial = ws + p->loss_partial_off;
+    h.gscale = 2.0f / ((float)p->S * (float)p->B * (float)p->Tout * (float)p->C);
+    return h;
+}
+
+// ---------------------------------------------------------------------------------------
+// forward: get_output (UnetAudioSeparator.py:85-144)
+// ---------------------------------------------------------------------------------------
+extern "C" int wun_forward(const wun_plan* p, const float* params, const float* mix_btc, float* ws,
+                           float* outputs, int training, void* stream) {
+    if (!p || !params || !mix_btc || !ws || !outputs) return fail(WUN_ERR_INVALID, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int L = p->L, Kd = p->cfg.filter_size, Ku = p->cfg.merge_filter_size;
+    const bool same = p->same;
+    const int padD = same ? (Kd - 1) / 2 : 0, padU = same ? (Ku - 1) / 2 : 0;
+
+    HIP_TRY(launch_btc_to_ncw(mix_btc, ws + p->mix_ncw.off, p->B, p->Tin, p->C, p->mix_ncw.pitch, s));
+
+    const Buf* x = &p->mix_ncw;
+    for (int i = 0; i < L; ++i) {                                   // :97-100
+        const DownShape& d = p->dsh[i];
+        const ConvLayer& cl = p->down[i];
+        if (same) {
+            ConvArgs a = conv_base(p);
+            set_src0(a, ws, *x, 0, d.cin);
+            a.Tin = d.t_in; a.shift = padD; a.W = params + cl.woff; a.bias = params + cl.boff;
+            a.KW = Kd; a.N = a.N0 = d.cout; a.Tout = d.t_conv; a.flags = F_LRELU;
+            set_dst0(a, ws, p->skip[i], 0, nullptr);
+            a.dec = ws + p->dec[i].off; a.decbs = p->dec[i].bs; a.decpitch = p->dec[i].pitch;
+            HIP_TRY(launch_conv(a, s));
+        } else {
+            // stride-2 conv straight into the decimated stream (odd outputs are never observed)
+            ConvArgs a = conv_base(p);
+            set_src0(a, ws, *x, 0, d.cin);
+            a.loader = LOADER_DEINT;
+            a.Tin = d.t_in; a.shift = 0; a.W = params + cl.woff; a.bias = params + cl.boff;
+            a.KW = Kd; a.N = a.N0 = d.cout; a.Tout = d.t_dec; a.flags = F_LRELU;
+            set_dst0(a, ws, p->dec[i], 0, nullptr);
+            HIP_TRY(launch_conv(a, s));
+            // full-rate conv only over the window the skip connection crops (Utils.py:104-123)
+            ConvArgs b = conv_base(p);
+            set_src0(b, ws, *x, d.cs, d.cin);
+            b.Tin = d.tc + Kd - 1; b.shift = 0; b.W = params + cl.woff; b.bias = params + cl.boff;
+            b.KW = Kd; b.N = b.N0 = d.cout; b.Tout = d.tc; b.flags = F_LRELU;
+            set_dst0(b, ws, p->skip[i], 0, nullptr);
+            HIP_TRY(launch_conv(b, s));
+        }
+        x = &p->dec[i];
+    }
+    {                                                               // :102
+        ConvArgs a = conv_base(p);
+        set_src0(a, ws, *x, 0, p->bott.Cin);
+        a.Tin = p->t_b_in; a.shift = padD; a.W = params + p->bott.woff; a.bias = params + p->bott.boff;
+        a.KW = Kd; a.N = a.N0 = p->c_b; a.Tout = p->t_b; a.flags = F_LRELU;
+        set_dst0(a, ws, p->bott_out, 0, nullptr);
+        HIP_TRY(launch_conv(a, s));
+    }
+    const Buf* cur = &p->bott_out;
+    for (int j = 0; j < L; ++j) {                                   // :107-125
+        const UpShape& u = p->ush[j];
+        UpsampleArgs ua;
+        memset(&ua, 0, sizeof(ua));
+        ua.x = ws + cur->off; ua.xbs = cur->bs; ua.xpitch = cur->pitch; ua.n = u.t_cur;
+        ua.y = ws + p->ups[j].off; ua.ybs = p->ups[j].bs; ua.ypitch = p->ups[j].pitch; ua.tup = u.t_up;
+        ua.w = p->interp[j] >= 0 ? params + p->interp[j] : nullptr;
+        ua.C = u.c_cur; ua.B = p->B; ua.context = p->cfg.context;
+        HIP_TRY(launch_upsample(ua, s));
+        ConvArgs a = conv_base(p);
+        set_src0(a, ws, p->skip[L - 1 - j], 0, u.c_skip);          // crop already applied when it was written
+        set_src1(a, ws, p->ups[j], 0, u.c_cur);
+        a.Tin = u.t_up; a.shift = padU; a.W = params + p->up[j].woff; a.bias = params + p->up[j].boff;
+        a.KW = Ku; a.N = a.N0 = u.cout; a.Tout = u.t_conv; a.flags = F_LRELU;
+        set_dst0(a, ws, p->upo[j], 0, nullptr);
+        HIP_TRY(launch_conv(a, s));
+        cur = &p->upo[j];
+    }
+    HeadArgs h = head_args(p, params, ws, outputs, training);
+    long long hoff[4] = {0, 0, 0, 0};
+    for (int i = 0; i < p->Sh; ++i) hoff[i] = p->head[i].woff;
+    HIP_TRY(launch_head_fwd_off(h, hoff, s));
+    return WUN_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// loss + backward
+// ---------------------------------------------------------------------------------------
+static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const ConvLayer& cl, float* ws,
+                     float* grads, hipStream_t s) {
+    const long long blk = (long long)cl.KW * cl.Cin * cl.Cout + cl.Cout;
+    int total = 0;
+    for (int i = 0; i < nparts; ++i) {
+        parts[i].nsplit = wgrad_pick_nsplit(parts[i]);
+        total += parts[i].nsplit;
+    }
+    if ((long long)total * blk > p->partial_floats) return fail(WUN_ERR_INVALID, "internal: wgrad partial buffer too small");
+    float* partial = ws + p->partial_off;
+    if (total == 1) {
+        parts[0].out = grads + cl.woff; parts[0].split_stride = blk;
+        HIP_TRY(launch_wgrad(parts[0], s));
+        return WUN_OK;
+    }
+    int done = 0;
+    for (int i = 0; i < nparts; ++i) {
+        parts[i].out = partial + (long long)done * blk;
+        parts[i].split_stride = blk;
+        HIP_TRY(launch_wgrad(parts[i], s));
+        done += parts[i].nsplit;
+    }
+    HIP_TRY(launch_reduce(partial, blk, total, grads + cl.woff, blk, s));
+    return WUN_OK;
+}
+
+extern "C" int wun_loss_backward(const wun_plan* p, const float* params, const float* mix_btc, float* ws,
+                                 const float* outputs, const float* targets, float* grads, float* loss,
+                                 void* stream) {
+    (void)mix_btc;
+    if (!p || !params || !ws || !outputs || !targets || !grads || !loss) return fail(WUN_ERR_INVALID, "null argument");
+    if (!p->wt.empty() && !p->dev_wt) return fail(WUN_ERR_HIP, "plan was created without a usable HIP device");
+    hipStream_t s = (hipStream_t)stream;
+    const int L = p->L, Kd = p->cfg.filter_size, Ku = p->cfg.merge_filter_size, Ko = p->cfg.output_filter_size;
+    const bool same = p->same;
+    const int padD = same ? (Kd - 1) / 2 : 0, padU = same ? (Ku - 1) / 2 : 0;
+    const int F = p->cfg.num_initial_filters, C = p->C;
+    int rc;
+
+    HIP_TRY(launch_make_wt(params, ws, p->dev_wt, (int)p->wt.size(), p->wt_max, s));
+
+    // ---- head: loss, d(pre-activation), d(feature map) ----
+    HeadArgs h = head_args(p, params, ws, const_cast<float*>(outputs), 1);
+    h.tgt = targets;
+    long long hoff[4] = {0, 0, 0, 0};
+    for (int i = 0; i < p->Sh; ++i) hoff[i] = p->head[i].woff;
+    HIP_TRY(launch_head_bwd_off(h, hoff, s));
+    HIP_TRY(launch_loss_finish(h.loss_partial, head_bwd_blocks(h),
+                               1.0f / ((float)p->S * (float)p->B * (float)p->Tout * (float)p->C), loss, s));
+    for (int sh = 0; sh < p->Sh; ++sh) {
+        WgradArgs w = wgrad_base(p);
+        wset_src0(w, ws, p->mix_ncw, p->in_crop_start, C);
+        wset_src1(w, ws, p->upo[L - 1], 0, F);
+        w.Tin = p->t_feat; w.shift = h.padl; w.KW = Ko;
+        wset_dz(w, h.dpre + (long long)sh * h.dps, h.dpbs, h.dppitch, C, p->Tout);
+        if ((rc = run_wgrad(p, &w, 1, p->head[sh], ws, grads, s))) return rc;
+    }
+
+    // ---- up path, last level first ----
+    for (int j = L - 1; j >= 0; --j) {
+        const UpShape& u = p->ush[j];
+        const int i = L - 1 - j;
+        {
+            WgradArgs w = wgrad_base(p);
+            wset_src0(w, ws, p->skip[i], 0, u.c_skip);
+            wset_src1(w, ws, p->ups[j], 0, u.c_cur);
+            w.Tin = u.t_up; w.shift = padU; w.KW = Ku;
+            wset_dz(w, ws + p->dz_upo[j].off, p->dz_upo[j].bs, p->dz_upo[j].pitch, u.cout, u.t_conv);
+            if ((rc = run_wgrad(p, &w, 1, p->up[j], ws, grads, s))) return rc;
+        }
+        {
+            ConvArgs a = conv_base(p);
+            set_src0(a, ws, p->dz_upo[j], 0, u.cout);
+            a.Tin = u.t_conv; a.shift = Ku - 1 - padU; a.W = ws + p->up[j].wt_full; a.KW = Ku;
+            a.N = u.c_skip + u.c_cur; a.N0 = u.c_skip; a.Tout = u.t_up;
+            set_dst0(a, ws, p->dz_skip[i], 0, &p->skip[i]);
+            set_dst1(a, ws, p->d_ups[j], 0, nullptr);
+            HIP_TRY(launch_conv(a, s));
+        }
+        {
+            const Buf& prev = (j == 0) ? p->bott_out : p->upo[j - 1];
+            const Buf& dzprev = (j == 0) ? p->dz_bott : p->dz_upo[j - 1];
+            UpsampleBwdArgs ub;
+            memset(&ub, 0, sizeof(ub));
+            ub.dy = ws + p->d_ups[j].off; ub.ybs = p->d_ups[j].bs; ub.ypitch = p->d_ups[j].pitch; ub.tup = u.t_up;
+            ub.x = ws + prev.off; ub.xbs = prev.bs; ub.xpitch = prev.pitch; ub.n = u.t_cur;
+            ub.dz = ws + dzprev.off;
+            ub.w = p->interp[j] >= 0 ? params + p->interp[j] : nullptr;
+            ub.dw = p->interp[j] >= 0 ? grads + p->interp[j] : nullptr;
+            ub.C = u.c_cur; ub.B = p->B; ub.context = p->cfg.context;
+            HIP_TRY(launch_upsample_bwd(ub, s));
+        }
+    }
+
+    // ---- bottleneck ----
+    {
+        WgradArgs w = wgrad_base(p);
+        wset_src0(w, ws, p->dec[L - 1], 0, p->bott.Cin);
+        w.Tin = p->t_b_in; w.shift = padD; w.KW = Kd;
+        wset_dz(w, ws + p->dz_bott.off, p->dz_bott.bs, p->dz_bott.pitch, p->c_b, p->t_b);
+        if ((rc = run_wgrad(p, &w, 1, p->bott, ws, grads, s))) return rc;
+        ConvArgs a = conv_base(p);
+        set_src0(a, ws, p->dz_bott, 0, p->c_b);
+        a.Tin = p->t_b; a.shift = Kd - 1 - padD; a.W = ws + p->bott.wt_full; a.KW = Kd;
+        a.N = a.N0 = p->bott.Cin; a.Tout = p->t_b_in;
+        if (same) {
+            set_dst0(a, ws, p->dz_skip[L - 1], 0, &p->skip[L - 1]);
+            a.ostride = 2; a.flags = F_ACCUM;
+        } else {
+            set_dst0(a, ws, p->dz_dec[L - 1], 0, &p->dec[L - 1]);
+        }
+        HIP_TRY(launch_conv(a, s));
+    }
+
+    // ---- down path ----
+    for (int i = L - 1; i >= 0; --i) {
+        const DownShape& d = p->dsh[i];
+        const ConvLayer& cl = p->down[i];
+        const Buf& x = (i == 0) ? p->mix_ncw : p->dec[i - 1];
+        if (same) {
+            WgradArgs w = wgrad_base(p);
+            wset_src0(w, ws, x, 0, d.cin);
+            w.Tin = d.t_in; w.shift = padD; w.KW = Kd;
+            wset_dz(w, ws + p->dz_skip[i].off, p->dz_skip[i].bs, p->dz_skip[i].pitch, d.cout, d.t_conv);
+            if ((rc = run_wgrad(p, &w, 1, cl, ws, grads, s))) return rc;
+            if (i > 0) {
+                ConvArgs a = conv_base(p);
+                set_src0(a, ws, p->dz_skip[i], 0, d.cout);
+                a.Tin = d.t_conv; a.shift = Kd - 1 - padD; a.W = ws + cl.wt_full; a.KW = Kd;
+                a.N = a.N0 = d.cin; a.Tout = d.t_in;
+                set_dst0(a, ws, p->dz_skip[i - 1], 0, &p->skip[i - 1]);
+                a.ostride = 2; a.flags = F_ACCUM;
+                HIP_TRY(launch_conv(a, s));
+            }
+        } else {
+            WgradArgs w[2];
+            w[0] = wgrad_base(p);
+            wset_src0(w[0], ws, x, 0, d.cin);
+            w[0].loader = LOADER_DEINT; w[0].Tin = d.t_in; w[0].shift = 0; w[0].KW = Kd;
+            wset_dz(w[0], ws + p->dz_dec[i].off, p->dz_dec[i].bs, p->dz_dec[i].pitch, d.cout, d.t_dec);
+            w[1] = wgrad_base(p);
+            wset_src0(w[1], ws, x, d.cs, d.cin);
+            w[1].Tin = d.tc + Kd - 1; w[1].shift = 0; w[1].KW = Kd;
+            wset_dz(w[1], ws + p->dz_skip[i].off, p->dz_skip[i].bs, p->dz_skip[i].pitch, d.cout, d.tc);
+            if ((rc = run_wgrad(p, w, 2, cl, ws, grads, s))) return rc;
+            if (i > 0) {
+                for (int ph = 0; ph < 2; ++ph) {       // transposed stride-2 conv, one output phase at a time
+                    ConvArgs a = conv_base(p);
+                    set_src0(a, ws, p->dz_dec[i], 0, d.cout);
+                    a.Tin = d.t_dec; a.KW = cl.Jp[ph]; a.shift = cl.Jp[ph] - 1; a.W = ws + cl.wt_ph[ph];
+                    a.N = a.N0 = d.cin; a.Tout = (d.t_in - ph + 1) / 2;
+                    set_dst0(a, ws, p->dz_dec[i - 1], ph, &p->dec[i - 1]);
+                    a.ostride = 2;
+                    HIP_TRY(launch_conv(a, s));
+                }
+                ConvArgs a = conv_base(p);
+                set_src0(a, ws, p->dz_skip[i], 0, d.cout);
+                a.Tin = d.tc; a.shift = Kd - 1; a.W = ws + cl.wt_full; a.KW = Kd;
+                a.N = a.N0 = d.cin; a.Tout = d.tc + Kd - 1;
+                set_dst0(a, ws, p->dz_dec[i - 1], d.cs, &p->dec[i - 1]);
+                a.flags = F_ACCUM;
+                HIP_TRY(launch_conv(a, s));
+            }
+        }
+    }
+    return WUN_OK;
+}
+
+extern "C" int wun_adam_step(const wun_plan* p, float* params, const float* grads, float* m, float* v,
+                             int64_t step, float lr, float beta1, float beta2, float eps, float grad_scale,
+                             void* stream) {
+    if (!p || !params || !grads || !m || !v) return fail(WUN_ERR_INVALID, "null argument");
+    if (step < 1) return fail(WUN_ERR_INVALID, "step is 1-based");
+    const double lr_t = (double)lr * std::sqrt(1.0 - std::pow((double)beta2, (double)step)) /
+                        (1.0 - std::pow((double)beta1, (double)step));
+    HIP_TRY(launch_adam(params, grads, m, v, p->arena, (float)lr_t, beta1, beta2, eps, grad_scale, (hipStream_t)stream));
+    return WUN_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// single operators
+// ---------------------------------------------------------------------------------------
+static void op_src(ConvArgs& a, const float* x, int C, int T) {
+    const int pitch = T;
+    a.src0 = x; a.bs0 = (long long)C * pitch; a.pitch0 = pitch; a.off0 = 0; a.C0 = C;
+}
+
+extern "C" int wun_op_conv1d(const float* x, const float* w, const float* bias, float* y, int batch, int cin,
+                             int cout, int k, int t_in, int t_out, int stride, int pad_left, int lrelu,
+                             void* stream) {
+    if (!x || !w || !y) return fail(WUN_ERR_INVALID, "null argument");
+    if (stride != 1 && stride != 2) return fail(WUN_ERR_UNSUPPORTED, "stride must be 1 or 2");
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = batch; a.ostride = 1;
+    op_src(a, x, cin, t_in);
+    a.loader = stride == 2 ? LOADER_DEINT : LOADER_DIRECT;
+    a.Tin = t_in; a.shift = pad_left; a.W = w; a.bias = bias; a.KW = k; a.N = a.N0 = cout; a.Tout = t_out;
+    a.flags = lrelu ? F_LRELU : 0;
+    a.dst0 = y; a.obs0 = (long long)cout * t_out; a.opitch0 = t_out;
+    HIP_TRY(launch_conv(a, (hipStream_t)stream));
+    return WUN_OK;
+}
+
+static WgradArgs op_wgrad_args(const float* x, const float* dz, int batch, int cin, int cout, int k, int t_in,
+                               int t_out, int stride, int pad_left) {
+    WgradArgs w;
+    memset(&w, 0, sizeof(w));
+    w.B = batch; w.loader = stride == 2 ? LOADER_DEINT : LOADER_DIRECT;
+    w.src0 = x; w.bs0 = (long long)cin * t_in; w.pitch0 = t_in; w.C0 = cin;
+    w.Tin = t_in; w.shift = pad_left; w.KW = k;
+    w.dz = dz; w.dzbs = (long long)cout * t_out; w.dzpitch = t_out; w.N = cout; w.Tq = t_out;
+    return w;
+}
+
+extern "C" int64_t wun_op_conv1d_wgrad_scratch(int batch, int cin, int cout, int k, int t_out) {
+    // worst case over both loaders
+    WgradArgs a = wgrad_shape_only(batch, cin, 0, k, LOADER_DIRECT, cout, t_out);
+    WgradArgs b = wgrad_shape_only(batch, cin, 0, k, LOADER_DEINT, cout, t_out);
+    const long long ns = std::max(wgrad_pick_nsplit(a), wgrad_pick_nsplit(b));
+    return ns * ((long long)k * cin * cout + cout);
+}
+
+extern "C" int wun_op_conv1d_wgrad(const float* x, const float* dz, float* dw, float* db, float* scratch,
+                                   int batch, int cin, int cout, int k, int t_in, int t_out, int stride,
+                                   int pad_left, void* stream) {
+    if (!x || !dz || !dw || !db || !scratch) return fail(WUN_ERR_INVALID, "null argument");
+    if (stride != 1 && stride != 2) return fail(WUN_ERR_UNSUPPORTED, "stride must be 1 or 2");
+    hipStream_t s = (hipStream_t)stream;
+    WgradArgs w = op_wgrad_args(x, dz, batch, cin, cout, k, t_in, t_out, stride, pad_left);
+    w.nsplit = wgrad_pick_nsplit(w);
+    const long long blk = (long long)k * cin * cout + cout;
+    w.out = scratch; w.split_stride = blk;
+    HIP_TRY(launch_wgrad(w, s));
+    HIP_TRY(launch_reduce(scratch, blk, w.nsplit, dw, (long long)k * cin * cout, s));
+    HIP_TRY(launch_reduce(scratch + (long long)k * cin * cout, blk, w.nsplit, db, cout, s));
+    return WUN_OK;
+}
+
+extern "C" int wun_op_conv1d_dgrad(const float* dz, const float* w, float* dx, float* wt_scratch, int batch,
+                                   int cin, int cout, int k, int t_in, int t_out, int stride, int pad_left,
+                                   void* stream) {
+    if (!dz || !w || !dx || !wt_scratch) return fail(WUN_ERR_INVALID, "null argument");
+    if (stride != 1 && stride != 2) return fail(WUN_ERR_UNSUPPORTED, "stride must be 1 or 2");
+    hipStream_t s = (hipStream_t)stream;
+    if (stride == 1) {
+        WtDesc d; d.src_off = 0; d.dst_off = 0; d.J = k; d.C = cin; d.N = cout; d.k_last = k - 1; d.k_step = 1;
+        HIP_TRY(launch_make_wt_one(w, wt_scratch, d, s));
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.B = batch; a.ostride = 1;
+        op_src(a, dz, cout, t_out);
+        a.Tin = t_out; a.shift = k - 1 - pad_left; a.W = wt_scratch; a.KW = k; a.N = a.N0 = cin; a.Tout = t_in;
+        a.dst0 = dx; a.obs0 = (long long)cin * t_in; a.opitch0 = t_in;
+        HIP_TRY(launch_conv(a, s));
+    } else {
+        if (pad_left != 0) return fail(WUN_ERR_UNSUPPORTED, "stride-2 dgrad supports pad_left == 0 only");
+        for (int ph = 0; ph < 2; ++ph) {
+            const int Jp = (k - ph + 1) / 2;
+            float* wt = wt_scratch + (long long)ph * k * cin * cout;
+            WtDesc d; d.src_off = 0; d.dst_off = 0; d.J = Jp; d.C = cin; d.N = cout;
+            d.k_last = 2 * (Jp - 1) + ph; d.k_step = 2;
+            if (Jp > 0) HIP_TRY(launch_make_wt_one(w, wt, d, s));
+            ConvArgs a;
+            memset(&a, 0, sizeof(a));
+            a.B = batch; a.ostride = 2;
+            op_src(a, dz, cout, t_out);
+            a.Tin = t_out; a.KW = Jp; a.shift = Jp - 1; a.W = wt; a.N = a.N0 = cin; a.Tout = (t_in - ph + 1) / 2;
+            a.dst0 = dx; a.obs0 = (long long)cin * t_in; a.opitch0 = t_in; a.ooff0 = ph;
+            HIP_TRY(launch_conv(a, s));
+        }
+    }
+    return WUN_OK;
+}
+
+extern "C" int wun_op_mfma_probe(const float* a, const float* b, float* d, void* stream) {
+    if (!a || !b || !d) return fail(WUN_ERR_INVALID, "null argument");
+    HIP_TRY(launch_mfma_probe(a, b, d, (hipStream_t)stream));
+    return WUN_OK;
+}
+
+extern "C" int wun_profile_begin(void) { prof_begin(); return WUN_OK; }
+
+extern "C" int wun_profile_end(char* json_out, int64_t capacity) {
+    const std::string js = prof_end();
+    if (!json_out || capacity < (int64_t)js.size() + 1) return fail(WUN_ERR_INVALID, "profile buffer too small");
+    memcpy(json_out, js.c_str(), js.size() + 1);
+    return WUN_OK;
+}
+
+extern "C" const char* wun_last_error(void) { return g_err.c_str(); }
+extern "C" const char* wun_version(void) { return "wun 0.1 (gfx950, fp32 MFMA 16x16x4)"; }

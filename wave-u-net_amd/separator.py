@@ -1,0 +1,234 @@
+"""Host-side mirror of the reference's separator object for the hot path.
+
+Same constructor / get_padding / get_output surface as
+/root/reference/Models/UnetAudioSeparator.py:9-144 (what Training.py:29-47, Test.py:15-34 and
+Evaluate.py:28-47 call), driving the gfx950 kernels in libwun.so through the C ABI of
+include/wun.h.  Because there is no tf.gradients here, the object additionally exposes
+`loss_and_gradients` (Training.py:50-63 + the backward implied by :77) and `adam_step`
+(tf.train.AdamOptimizer, Training.py:77).
+
+torch is used for device memory, streams and torch.distributed only.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import finalize
+
+_UPS = {"linear": 0, "learned": 1}
+_OUT = {"direct": 0, "difference": 1}
+_ACT = {"tanh": 0, "linear": 1}
+
+
+def _wun_config(cfg):
+    for key, table in (("upsampling", _UPS), ("output_type", _OUT), ("output_activation", _ACT)):
+        if cfg[key] not in table:
+            raise NotImplementedError("%s=%r" % (key, cfg[key]))   # UnetAudioSeparator.py:136,144
+    return _lib.WunConfig(
+        cfg["num_layers"], cfg["num_initial_filters"], cfg["filter_size"], cfg["merge_filter_size"],
+        cfg["input_filter_size"], cfg["output_filter_size"], _UPS[cfg["upsampling"]],
+        _OUT[cfg["output_type"]], 1 if cfg["context"] else 0, len(cfg["source_names"]),
+        1 if cfg["mono_downmix"] else 2, _ACT[cfg["output_activation"]])
+
+
+class _Plan(object):
+    def __init__(self, lib, wcfg, batch, frames):
+        self.lib = lib
+        self.handle = C.c_void_p()
+        _lib.check(lib.wun_plan_create(C.byref(wcfg), batch, frames, C.byref(self.handle)))
+        self.info = _lib.WunPlanInfo()
+        _lib.check(lib.wun_plan_query(self.handle, C.byref(self.info)))
+        self.tensors = []
+        for i in range(self.info.num_tensors):
+            ti = _lib.WunTensorInfo()
+            _lib.check(lib.wun_plan_tensor(self.handle, i, C.byref(ti)))
+            self.tensors.append((ti.name.decode(), int(ti.offset),
+                                 tuple(int(ti.shape[k]) for k in range(ti.ndim))))
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.lib.wun_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class UnetAudioSeparator(object):
+    """U-Net separator network on raw waveforms (UnetAudioSeparator.py:9-13)."""
+
+    def __init__(self, model_config, device=None, seed=1337):
+        cfg = finalize(model_config) if "source_names" not in model_config else dict(model_config)
+        self.model_config = cfg
+        self.num_layers = cfg["num_layers"]                      # UnetAudioSeparator.py:20-32
+        self.num_initial_filters = cfg["num_initial_filters"]
+        self.filter_size = cfg["filter_size"]
+        self.merge_filter_size = cfg["merge_filter_size"]
+        self.input_filter_size = cfg["input_filter_size"]
+        self.output_filter_size = cfg["output_filter_size"]
+        self.upsampling = cfg["upsampling"]
+        self.output_type = cfg["output_type"]
+        self.context = cfg["context"]
+        self.padding = "valid" if cfg["context"] else "same"
+        self.source_names = list(cfg["source_names"])
+        self.num_channels = 1 if cfg["mono_downmix"] else 2
+        self.output_activation = cfg["output_activation"]
+
+        self._lib = _lib.load()                                   # raises if libwun.so is missing
+        self._wcfg = _wun_config(cfg)
+        self._seed = seed
+        self._device = torch.device(device) if device is not None else None
+        self._plans = {}
+        self._active = None          # plan of the last get_output
+        self.params = None           # flat float32 arena (TF creation order)
+        self.grads = self.adam_m = self.adam_v = None
+        self.global_step = 0
+        self._ws = {}
+        self._outs = {}
+        self._last_mix = None
+
+    # ------------------------------------------------------------------ shapes
+    def get_padding(self, shape):
+        """UnetAudioSeparator.py:34-83.  shape = [batch, desired_output_frames, *]."""
+        fin, fout = C.c_int64(), C.c_int64()
+        _lib.check(self._lib.wun_get_padding(C.byref(self._wcfg), int(shape[1]), C.byref(fin),
+                                             C.byref(fout)))
+        b = int(shape[0])
+        return (np.array([b, fin.value, self.num_channels], dtype=np.int64),
+                np.array([b, fout.value, self.num_channels], dtype=np.int64))
+
+    # ------------------------------------------------------------------ variables
+    def _plan(self, batch, frames):
+        key = (int(batch), int(frames))
+        if key not in self._plans:
+            self._plans[key] = _Plan(self._lib, self._wcfg, key[0], key[1])
+        return self._plans[key]
+
+    def _dev(self):
+        if self._device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("wave-u-net_amd needs an MI355X (no CPU fallback)")
+            self._device = torch.device("cuda", torch.cuda.current_device())
+        return self._device
+
+    def variable_table(self, batch=1, frames=None):
+        """[(tf_name, offset, shape)] in TF creation order."""
+        if frames is None:
+            frames = int(self.get_padding([batch, 1 if self.context else 2 ** self.num_layers, 0])[0][1])
+        return list(self._plan(batch, frames).tensors)
+
+    def _ensure_variables(self, plan):
+        if self.params is not None:
+            return
+        n = int(plan.info.arena_floats)
+        host = np.zeros(n, dtype=np.float32)
+        rng = np.random.default_rng(self._seed)
+        for name, off, shp in plan.tensors:              # glorot-uniform / zero bias (TF defaults)
+            size = int(np.prod(shp))
+            if name.endswith("/bias"):
+                continue
+            if len(shp) == 1:
+                fan_in = fan_out = shp[0]
+            else:
+                rf = int(np.prod(shp[:-2]))
+                fan_in, fan_out = shp[-2] * rf, shp[-1] * rf
+            lim = math.sqrt(6.0 / (fan_in + fan_out))
+            host[off:off + size] = rng.uniform(-lim, lim, size=size).astype(np.float32)
+        dev = self._dev()
+        self.params = torch.from_numpy(host).to(dev)
+        self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.adam_m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.adam_v = torch.zeros(n, dtype=torch.float32, device=dev)
+
+    def variables(self):
+        """dict tf_name -> tensor view into the flat arena."""
+        plan = self._active or next(iter(self._plans.values()))
+        return {name: self.params[off:off + int(np.prod(shp))].view(*shp)
+                for name, off, shp in plan.tensors}
+
+    def gradients(self):
+        plan = self._active or next(iter(self._plans.values()))
+        return {name: self.grads[off:off + int(np.prod(shp))].view(*shp)
+                for name, off, shp in plan.tensors}
+
+    def load_variables(self, named):
+        """named: dict or list of (tf_name, array).  Requires a plan (call get_output or
+        variable_table first)."""
+        items = named.items() if isinstance(named, dict) else named
+        plan = self._active or next(iter(self._plans.values()))
+        self._ensure_variables(plan)
+        index = {name: (off, shp) for name, off, shp in plan.tensors}
+        for name, val in items:
+            off, shp = index[name]
+            t = torch.as_tensor(np.asarray(val), dtype=torch.float32).reshape(-1)
+            assert t.numel() == int(np.prod(shp)), (name, t.shape, shp)
+            self.params[off:off + t.numel()].copy_(t)
+
+    # ------------------------------------------------------------------ forward
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self._dev()).cuda_stream)
+
+    def get_output(self, input, training, return_spectrogram=False, reuse=True):
+        """UnetAudioSeparator.py:85-144.  input: [batch, num_samples, num_channels] float32
+        (torch tensor on the GPU, or anything np.asarray accepts).  Returns a dict
+        source_name -> [batch, num_out_samples, num_channels] torch tensor (views of one
+        buffer that is overwritten by the next call with the same shape)."""
+        dev = self._dev()
+        if not torch.is_tensor(input):
+            input = torch.as_tensor(np.asarray(input, dtype=np.float32))
+        mix = input.to(device=dev, dtype=torch.float32).contiguous()
+        if mix.dim() != 3 or mix.shape[2] != self.num_channels:
+            raise ValueError("input must be [batch, samples, %d]" % self.num_channels)
+        plan = self._plan(mix.shape[0], mix.shape[1])
+        self._ensure_variables(plan)
+        key = (mix.shape[0], mix.shape[1])
+        if key not in self._ws:
+            self._ws[key] = torch.empty(int(plan.info.workspace_floats), dtype=torch.float32, device=dev)
+            self._outs[key] = torch.empty((len(self.source_names), mix.shape[0],
+                                           int(plan.info.output_frames), self.num_channels),
+                                          dtype=torch.float32, device=dev)
+        ws, outs = self._ws[key], self._outs[key]
+        _lib.check(self._lib.wun_forward(plan.handle, self.params.data_ptr(), mix.data_ptr(),
+                                         ws.data_ptr(), outs.data_ptr(), 1 if training else 0,
+                                         self._stream()))
+        self._active, self._last_mix, self._last_key = plan, mix, key
+        self._last_training = bool(training)
+        return {name: outs[i] for i, name in enumerate(self.source_names)}
+
+    # ------------------------------------------------------------------ training step pieces
+    def loss_and_gradients(self, targets):
+        """MSE loss averaged over sources (Training.py:50-63) and its gradient w.r.t. every
+        separator variable.  targets: dict source_name -> [B, Tout, C] or a stacked
+        [S, B, Tout, C] tensor.  Must follow get_output(training=True).  Returns the loss as
+        a 0-dim GPU tensor (no host sync)."""
+        if self._active is None or not self._last_training:
+            raise RuntimeError("call get_output(..., training=True) first")
+        dev = self._dev()
+        if isinstance(targets, dict):
+            tg = torch.stack([torch.as_tensor(targets[n]).to(dev, torch.float32) for n in self.source_names])
+        else:
+            tg = targets.to(dev, torch.float32)
+        tg = tg.contiguous()
+        outs = self._outs[self._last_key]
+        if tuple(tg.shape) != tuple(outs.shape):
+            raise ValueError("targets shape %s != outputs shape %s" % (tuple(tg.shape), tuple(outs.shape)))
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        _lib.check(self._lib.wun_loss_backward(
+            self._active.handle, self.params.data_ptr(), self._last_mix.data_ptr(),
+            self._ws[self._last_key].data_ptr(), outs.data_ptr(), tg.data_ptr(),
+            self.grads.data_ptr(), loss.data_ptr(), self._stream()))
+        return loss
+
+    def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+        """tf.train.AdamOptimizer(learning_rate=lr) update (Training.py:77) + global_step += 1."""
+        self.global_step += 1
+        _lib.check(self._lib.wun_adam_step(
+            self._active.handle, self.params.data_ptr(), self.grads.data_ptr(),
+            self.adam_m.data_ptr(), self.adam_v.data_ptr(), self.global_step, lr, beta1, beta2, eps,
+            grad_scale, self._stream()))
+
+    def plan_info(self):
+        return self._active.info if self._active is not None else None

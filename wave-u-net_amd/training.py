@@ -1,0 +1,112 @@
+"""Training loop with the shape of the reference's Training.train
+(/root/reference/Training.py:24-121): build the separator once, run `epoch_it` steps of
+{forward, MSE loss, backward, Adam}, count global_step, return a checkpoint path.
+
+The reference feeds the step from a tf.data pipeline over MUSDB (Datasets.py) -- out of
+scope here; `batch_source` is any callable returning (mix [B,Tin,C], targets [S,B,Tout,C])
+GPU tensors honouring that pipeline's output contract (float32, mix = sum of sources,
+targets centre-cropped).  `synthetic_source` is the benchmark's generator.
+"""
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+from .parallel import GradAllReducer, broadcast_parameters, init_distributed
+from .separator import UnetAudioSeparator
+
+
+def synthetic_source(model_config, batch, t_in, t_out, device, seed=1337):
+    """Band-limited noise sources (9-tap moving average of U(-1,1)), mix = sum of sources,
+    targets = centre crop (Utils.crop_sample, Utils.py:38-42).  Generated once on the GPU and
+    reused, so the timed loop has its inputs resident in HBM."""
+    S, C = len(model_config["source_names"]), 1 if model_config["mono_downmix"] else 2
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    srcs = []
+    for _ in range(S):
+        w = torch.rand((batch, C, t_in + 8), generator=gen) * 2 - 1
+        sm = torch.nn.functional.avg_pool1d(w, 9, stride=1)
+        sm = sm * ((0.9 / S) / sm.abs().max().clamp_min(1e-9))
+        srcs.append(sm.permute(0, 2, 1).contiguous())
+    src = torch.stack(srcs)                           # [S, B, Tin, C]
+    mix = src.sum(0).to(device)
+    pad = (t_in - t_out) // 2
+    targets = src[:, :, pad:t_in - pad, :].contiguous().to(device) if pad > 0 else src.to(device)
+
+    def source():
+        return mix, targets
+    return source
+
+
+class Trainer(object):
+    """One process per GPU.  step() = sess.run([separator_solver, ...]) of Training.py:105."""
+
+    def __init__(self, model_config, batch_size=None, device=None, seed=1337, bucket_mib=16.0):
+        self.cfg = model_config
+        self.rank, self.local_rank, self.world = init_distributed()
+        if device is None:
+            device = "cuda:%d" % self.local_rank
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.sep = UnetAudioSeparator(model_config, device=self.device, seed=seed)
+        self.batch = batch_size or model_config["batch_size"]
+        in_shape, out_shape = self.sep.get_padding(np.array([self.batch, model_config["num_frames"], 0]))
+        self.t_in, self.t_out = int(in_shape[1]), int(out_shape[1])
+        plan = self.sep._plan(self.batch, self.t_in)
+        self.sep._active = plan
+        self.sep._ensure_variables(plan)
+        broadcast_parameters(self.sep.params)
+        self.reducer = GradAllReducer(plan.tensors, plan.info.arena_floats, bucket_mib)
+        self.lr = model_config["init_sup_sep_lr"]
+
+    def step(self, mix, targets):
+        self.sep.get_output(mix, True)
+        loss = self.sep.loss_and_gradients(targets)
+        self.reducer.all_reduce(self.sep.grads)
+        self.sep.adam_step(self.lr, grad_scale=self.reducer.grad_scale)
+        return loss
+
+
+def train(model_config, experiment_id, load_model=None, batch_source=None, log_every=100):
+    """Training.train(model_config, experiment_id, load_model=None) -> save_path
+    (Training.py:24-25,121)."""
+    if model_config["network"] != "unet":
+        raise NotImplementedError(model_config["network"])         # Training.py:28-33
+    tr = Trainer(model_config)
+    if load_model is not None:
+        state = np.load(load_model)
+        tr.sep.load_variables({k: state[k] for k in state.files if k.startswith("separator/")})
+        if "adam_m" in state.files:
+            tr.sep.adam_m.copy_(torch.from_numpy(state["adam_m"]))
+            tr.sep.adam_v.copy_(torch.from_numpy(state["adam_v"]))
+        tr.sep.global_step = int(state["global_step"])
+    if batch_source is None:
+        batch_source = synthetic_source(model_config, tr.batch, tr.t_in, tr.t_out, tr.device,
+                                        seed=1337 + tr.rank)
+    log_dir = os.path.join(model_config["log_dir"], str(experiment_id))
+    if tr.rank == 0:
+        os.makedirs(log_dir, exist_ok=True)
+    log = open(os.path.join(log_dir, "train.jsonl"), "a") if tr.rank == 0 else None
+    t0 = time.time()
+    for it in range(model_config["epoch_it"]):                      # Training.py:103-109
+        mix, targets = batch_source()
+        loss = tr.step(mix, targets)
+        if log is not None and (it % log_every == 0 or it == model_config["epoch_it"] - 1):
+            log.write(json.dumps({"global_step": tr.sep.global_step, "sep_loss": float(loss.item()),
+                                  "elapsed_s": time.time() - t0}) + "\n")
+            log.flush()
+    torch.cuda.synchronize()
+    save_path = None
+    if tr.rank == 0:                                                # Training.py:113
+        ckpt_dir = os.path.join(model_config["model_base_dir"], str(experiment_id))
+        os.makedirs(ckpt_dir, exist_ok=True)
+        save_path = os.path.join(ckpt_dir, "%s-%d.npz" % (experiment_id, tr.sep.global_step))
+        arrays = {n: v.detach().cpu().numpy() for n, v in tr.sep.variables().items()}
+        arrays["adam_m"] = tr.sep.adam_m.cpu().numpy()
+        arrays["adam_v"] = tr.sep.adam_v.cpu().numpy()
+        arrays["global_step"] = np.int64(tr.sep.global_step)
+        np.savez(save_path, **arrays)
+        log.close()
+    return save_path
