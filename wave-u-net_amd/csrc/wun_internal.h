@@ -10,7 +10,7 @@ namespace wun {
 enum { LOADER_DIRECT = 0, LOADER_DEINT = 1 };
 
 // Epilogue flag bits
-enum { F_LRELU = 1, F_ACCUM = 2 };
+enum { F_LRELU = 1, F_ACCUM = 2, F_VEC4 = 4 };
 
 // One implicit-GEMM 1-D convolution launch.  The input is a virtual channel-concat of
 // up to two NCW sources, zero outside [0, Tin) (this is how crop+concat, 'same' zero
@@ -45,6 +45,8 @@ struct ConvArgs {
     int flags;
     int B;
     int loader;
+    int cps;         // split-K: channel chunks per split (set by the launcher)
+    float* part;     // split-K partial buffer (set by the launcher) or null
 };
 
 // Weight/bias gradient launch:  P[split][ (k*C + c)*N + n ] and bias row P[split][KW*C*N + n]
@@ -104,7 +106,7 @@ struct WtDesc {      // dst[j][n][c] = src[k_last - j*k_step][c][n]
 // ---- launchers (wun_kernels.hip) ---------------------------------------------------
 size_t conv_lds_bytes(const ConvArgs& a, int variant);
 int  conv_pick_variant(const ConvArgs& a);
-hipError_t launch_conv(const ConvArgs& a, hipStream_t s);
+hipError_t launch_conv(const ConvArgs& a, float* part, long long part_cap, hipStream_t s);
 double conv_flops(const ConvArgs& a);        // useful FLOPs (2*MACs) of the launch
 
 int  wgrad_pick_nsplit(const WgradArgs& a);

@@ -102,12 +102,31 @@ std::string prof_end() {
 // =====================================================================================
 // implicit-GEMM conv
 // =====================================================================================
-template <int MT, int NW, int WT, int WN, int CK>
+// Workgroup = 4 waves; tile = (WT*MT*16 time) x (WN*NW*16 cout).  Per channel chunk (CK LDS
+// rows) the input window + halo and the weight slab [J][CK][NT] are staged through
+// REGISTERS one chunk ahead (global loads of chunk c+1 are in flight while the MFMAs of
+// chunk c run; they are written to LDS after the barrier), weights as 16-byte loads.
+// Low-parallelism launches (deep levels: few time tiles) are split over channel chunks
+// (split-K): raw partial tiles go to a scratch buffer and conv_splitk_epilogue_kernel sums
+// them in a fixed order and applies the epilogue.
+#define WUN_JMAX 15
+
+template <int MT, int NW, int WT, int WN, int CK, bool VECW>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int nNT, int J,
                                                         int XP, int WP) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TT = WT * MT * 16;
     constexpr int NT = WN * NW * 16;
+    constexpr int NT4 = NT / 4;
+    constexpr int CH = CK / 2;
+    // staging trip counts (compile time, sized for J <= WUN_JMAX)
+    constexpr int TPR = 256 / CK;                                   // DIRECT: threads per LDS row
+    constexpr int XIT_D = (TT + WUN_JMAX - 1 + TPR - 1) / TPR;
+    constexpr int TPC = 256 / CH;                                   // DEINT: threads per channel
+    constexpr int XIT_I = (2 * (TT + (WUN_JMAX + 1) / 2 - 1) + TPC - 1) / TPC;
+    constexpr int XIT = XIT_D > XIT_I ? XIT_D : XIT_I;
+    constexpr int WIT = (WUN_JMAX * CK * NT4 + 255) / 256;
+
     float* Xs = lds;
     float* Ws = lds + CK * XP;
 
@@ -117,15 +136,23 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bid = blockIdx.x;
     const int nt = bid % nNT; bid /= nNT;
-    const int tt = bid % nTT;
-    const int b = bid / nTT;
+    const int tt = bid % nTT; bid /= nTT;
+    const int b = bid % a.B;
+    const int ksp = bid / a.B;
     const int q0 = tt * TT, n0 = nt * NT;
     const int wt0 = (wave % WT) * MT * 16;
     const int wn0 = (wave / WT) * NW * 16;
     const int Ctot = a.C0 + a.C1;
     const bool deint = (a.loader == LOADER_DEINT);
     const int UW = TT + J - 1;
-    const int CKC = deint ? CK / 2 : CK;       // input channels per chunk
+    const int CKC = deint ? CH : CK;                 // input channels per chunk
+    const int nchunks = (Ctot + CKC - 1) / CKC;
+    const int ch_lo = ksp * a.cps;
+    int ch_hi = ch_lo + a.cps;
+    if (ch_hi > nchunks) ch_hi = nchunks;
+
+    const float* src0b = a.src0 + (long long)b * a.bs0 + a.off0;
+    const float* src1b = (a.src1 != nullptr) ? a.src1 + (long long)b * a.bs1 + a.off1 : src0b;
 
     f32x4 acc[MT][NW];
 #pragma unroll
@@ -133,56 +160,104 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
 #pragma unroll
         for (int n = 0; n < NW; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int c0 = 0; c0 < Ctot; c0 += CKC) {
-        __syncthreads();
-        // ---- stage the input window (with halo) ----
+    float xreg[XIT];
+    f32x4 wreg[WIT];          // VECW: one 16-byte load each; else 4 scalar loads each
+
+    // ---- global -> registers for one chunk ----
+    auto load_chunk = [&](int chunk) {
+        const int c0 = chunk * CKC;
         if (!deint) {
-            constexpr int TPR = 256 / CK;
             const int r = tid / TPR, lr = tid % TPR;
             const int c = c0 + r;
-            const float* p = nullptr;
-            if (c < a.C0) p = a.src0 + (long long)b * a.bs0 + (long long)c * a.pitch0 + a.off0;
-            else if (c < Ctot) p = a.src1 + (long long)b * a.bs1 + (long long)(c - a.C0) * a.pitch1 + a.off1;
+            const bool cok = c < Ctot;
+            const float* p = (!cok || c < a.C0) ? src0b + (long long)(cok ? c : 0) * a.pitch0
+                                                : src1b + (long long)(c - a.C0) * a.pitch1;
             const int tbase = q0 - a.shift;
-            for (int u = lr; u < UW; u += TPR) {
+#pragma unroll
+            for (int i = 0; i < XIT_D; ++i) {
+                const int u = lr + i * TPR;
                 const int t = tbase + u;
-                float v = 0.f;
-                if (p != nullptr && t >= 0 && t < a.Tin) v = p[t];
-                Xs[r * XP + u] = v;
+                const bool ok = cok && u < UW && t >= 0 && t < a.Tin;
+                int tc = t < 0 ? 0 : t;
+                if (tc > a.Tin - 1) tc = a.Tin - 1;
+                const float v = p[tc];
+                xreg[i] = ok ? v : 0.f;
             }
         } else {
-            constexpr int CH = CK / 2;
-            constexpr int TPR = 256 / CH;
-            const int cc = tid / TPR, le = tid % TPR;
+            const int cc = tid / TPC, le = tid % TPC;
             const int c = c0 + cc;
-            const float* p = nullptr;
-            if (c < a.C0) p = a.src0 + (long long)b * a.bs0 + (long long)c * a.pitch0 + a.off0;
-            else if (c < Ctot) p = a.src1 + (long long)b * a.bs1 + (long long)(c - a.C0) * a.pitch1 + a.off1;
+            const bool cok = c < Ctot;
+            const float* p = (!cok || c < a.C0) ? src0b + (long long)(cok ? c : 0) * a.pitch0
+                                                : src1b + (long long)(c - a.C0) * a.pitch1;
             const int tbase = 2 * q0 - a.shift;
-            for (int e = le; e < 2 * UW; e += TPR) {
+#pragma unroll
+            for (int i = 0; i < XIT_I; ++i) {
+                const int e = le + i * TPC;
                 const int t = tbase + e;
-                float v = 0.f;
-                if (p != nullptr && t >= 0 && t < a.Tin) v = p[t];
-                Xs[((e & 1) * CH + cc) * XP + (e >> 1)] = v;
+                const bool ok = cok && e < 2 * UW && t >= 0 && t < a.Tin;
+                int tc = t < 0 ? 0 : t;
+                if (tc > a.Tin - 1) tc = a.Tin - 1;
+                const float v = p[tc];
+                xreg[i] = ok ? v : 0.f;
             }
         }
-        // ---- stage the weight slab [J][CK][NT] ----
-        for (int row = tid >> 4; row < J * CK; row += 16) {
+#pragma unroll
+        for (int i = 0; i < WIT; ++i) {
+            const int f = tid + i * 256;
+            const int row = f / NT4, c4 = f % NT4;
             const int j = row / CK, r = row % CK;
-            const float* wp = nullptr;
-            if (!deint) {
-                const int c = c0 + r;
-                if (c < Ctot) wp = a.W + ((long long)j * Ctot + c) * a.N + n0;
+            int k, c;
+            if (!deint) { k = j; c = c0 + r; }
+            else { k = 2 * j + r / CH; c = c0 + r % CH; }
+            const bool rok = row < J * CK && c < Ctot && k < a.KW;
+            if constexpr (VECW) {
+                const bool ok = rok && n0 + c4 * 4 < a.N;
+                const float* wp = a.W + (ok ? ((long long)k * Ctot + c) * a.N + n0 + c4 * 4 : 0);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(wp);
+                wreg[i] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
             } else {
-                const int ph = r / (CK / 2), cc = r % (CK / 2);
-                const int k = 2 * j + ph, c = c0 + cc;
-                if (k < a.KW && c < Ctot) wp = a.W + ((long long)k * Ctot + c) * a.N + n0;
+                const float* wrow = a.W + (rok ? ((long long)k * Ctot + c) * a.N : 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int col = n0 + c4 * 4 + e;
+                    const bool ok = rok && col < a.N;
+                    const float v = wrow[ok ? col : 0];
+                    wreg[i][e] = ok ? v : 0.f;
+                }
             }
-            for (int n = tid & 15; n < NT; n += 16)
-                Ws[row * WP + n] = (wp != nullptr && n0 + n < a.N) ? wp[n] : 0.f;
         }
+    };
+    // ---- registers -> LDS ----
+    auto store_chunk = [&]() {
+        if (!deint) {
+            const int r = tid / TPR, lr = tid % TPR;
+#pragma unroll
+            for (int i = 0; i < XIT_D; ++i) {
+                const int u = lr + i * TPR;
+                if (u < UW) Xs[r * XP + u] = xreg[i];
+            }
+        } else {
+            const int cc = tid / TPC, le = tid % TPC;
+#pragma unroll
+            for (int i = 0; i < XIT_I; ++i) {
+                const int e = le + i * TPC;
+                if (e < 2 * UW) Xs[((e & 1) * CH + cc) * XP + (e >> 1)] = xreg[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WIT; ++i) {
+            const int f = tid + i * 256;
+            const int row = f / NT4, c4 = f % NT4;
+            if (row < J * CK) *reinterpret_cast<f32x4*>(&Ws[row * WP + c4 * 4]) = wreg[i];
+        }
+    };
+
+    if (ch_lo < ch_hi) load_chunk(ch_lo);
+    for (int chunk = ch_lo; chunk < ch_hi; ++chunk) {
+        __syncthreads();                 // every wave is done reading the previous chunk
+        store_chunk();
         __syncthreads();
-        // ---- MFMA over (tap, channel-quad) ----
+        if (chunk + 1 < ch_hi) load_chunk(chunk + 1);   // in flight during the MFMAs below
         for (int j = 0; j < J; ++j) {
             const float* xa = Xs + lg * XP + wt0 + li + j;
             const float* wb = Ws + (j * CK + lg) * WP + wn0 + li;
@@ -202,9 +277,27 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
         }
     }
 
+    // ---- split-K: raw partial tile, epilogue runs in conv_splitk_epilogue_kernel ----
+    if (a.part != nullptr) {
+        const int TP = (a.Tout + 3) & ~3;
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            const int ncol = n0 + wn0 + n * 16 + li;
+            if (ncol >= a.N) continue;
+            float* prow = a.part + (((long long)ksp * a.B + b) * a.N + ncol) * TP;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int q = q0 + wt0 + m * 16 + lg * 4;
+                if (q < TP) *reinterpret_cast<f32x4*>(&prow[q]) = acc[m][n];
+            }
+        }
+        return;
+    }
+
     // ---- epilogue ----
     const bool lrelu = (a.flags & F_LRELU) != 0;
     const bool accum = (a.flags & F_ACCUM) != 0;
+    const bool vec = (a.flags & F_VEC4) != 0;
 #pragma unroll
     for (int n = 0; n < NW; ++n) {
         const int ncol = n0 + wn0 + n * 16 + li;
@@ -223,53 +316,114 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int q = q0 + wt0 + m * 16 + lg * 4;
+            if (vec && q + 3 < a.Tout) {
+                f32x4 v = acc[m][n];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (q + r < a.Tout) {
-                    float v = acc[m][n][r] + bvv;
-                    if (lrelu) v = fmaxf(0.2f * v, v);
-                    const long long idx = rowbase + (long long)(q + r) * a.ostride;
-                    if (msk != nullptr) v *= (msk[idx] > 0.f) ? 1.f : 0.2f;
-                    if (accum) v += dst[idx];
-                    dst[idx] = v;
-                    if (decrow != nullptr && ((q + r) & 1) == 0) decrow[(q + r) >> 1] = v;
+                for (int r = 0; r < 4; ++r) {
+                    v[r] += bvv;
+                    if (lrelu) v[r] = fmaxf(0.2f * v[r], v[r]);
+                }
+                const long long idx = rowbase + q;
+                if (msk != nullptr) {
+                    const f32x4 mk = *reinterpret_cast<const f32x4*>(&msk[idx]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= (mk[r] > 0.f) ? 1.f : 0.2f;
+                }
+                if (accum) {
+                    const f32x4 old = *reinterpret_cast<const f32x4*>(&dst[idx]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += old[r];
+                }
+                *reinterpret_cast<f32x4*>(&dst[idx]) = v;
+                if (decrow != nullptr) {
+                    decrow[q >> 1] = v[0];
+                    decrow[(q >> 1) + 1] = v[2];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (q + r < a.Tout) {
+                        float v = acc[m][n][r] + bvv;
+                        if (lrelu) v = fmaxf(0.2f * v, v);
+                        const long long idx = rowbase + (long long)(q + r) * a.ostride;
+                        if (msk != nullptr) v *= (msk[idx] > 0.f) ? 1.f : 0.2f;
+                        if (accum) v += dst[idx];
+                        dst[idx] = v;
+                        if (decrow != nullptr && ((q + r) & 1) == 0) decrow[(q + r) >> 1] = v;
+                    }
                 }
             }
         }
     }
 }
 
+// sums the split-K partial tiles in a fixed order and applies the conv epilogue
+__global__ void conv_splitk_epilogue_kernel(ConvArgs a, int ksplit) {
+    const int TP = (a.Tout + 3) & ~3;
+    const long long total = (long long)a.B * a.N * a.Tout;
+    const bool lrelu = (a.flags & F_LRELU) != 0;
+    const bool accum = (a.flags & F_ACCUM) != 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % a.Tout);
+        const long long bn = i / a.Tout;
+        const int ncol = (int)(bn % a.N), b = (int)(bn / a.N);
+        float v = 0.f;
+        for (int ks = 0; ks < ksplit; ++ks)
+            v += a.part[(((long long)ks * a.B + b) * a.N + ncol) * TP + q];
+        if (a.bias != nullptr) v += a.bias[ncol];
+        if (lrelu) v = fmaxf(0.2f * v, v);
+        float* dst; const float* msk; long long idx;
+        if (ncol < a.N0) {
+            idx = (long long)b * a.obs0 + (long long)ncol * a.opitch0 + a.ooff0 + (long long)q * a.ostride;
+            dst = a.dst0; msk = a.msk0;
+        } else {
+            idx = (long long)b * a.obs1 + (long long)(ncol - a.N0) * a.opitch1 + a.ooff1 + (long long)q * a.ostride;
+            dst = a.dst1; msk = a.msk1;
+        }
+        if (msk != nullptr) v *= (msk[idx] > 0.f) ? 1.f : 0.2f;
+        if (accum) v += dst[idx];
+        dst[idx] = v;
+        if (a.dec != nullptr && ncol < a.N0 && (q & 1) == 0)
+            a.dec[(long long)b * a.decbs + (long long)ncol * a.decpitch + (q >> 1)] = v;
+    }
+}
+
 // variant table -------------------------------------------------------------------------
 struct ConvVariant { int MT, NW, WT, WN, CK; };
 static const ConvVariant kConvVariants[] = {
-    {4, 2, 4, 1, 8},   // 0: 256 x 32
-    {4, 3, 4, 1, 8},   // 1: 256 x 48
-    {4, 4, 4, 1, 8},   // 2: 256 x 64
-    {4, 5, 4, 1, 8},   // 3: 256 x 80
-    {4, 6, 4, 1, 8},   // 4: 256 x 96
-    {2, 3, 2, 2, 8},   // 5:  64 x 96
-    {1, 2, 1, 4, 8},   // 6:  16 x 128
-    {4, 2, 4, 1, 4},   // 7: 256 x 32, 4-channel chunks (1- or 2-channel audio input)
-    {1, 3, 2, 2, 8},   // 8:  32 x 96
+    {4, 2, 4, 1, 8}, {4, 3, 4, 1, 8}, {4, 4, 4, 1, 8}, {4, 5, 4, 1, 8},   //  0..3 : 256 x 32/48/64/80
+    {2, 2, 4, 1, 8}, {2, 3, 4, 1, 8}, {2, 4, 4, 1, 8}, {2, 5, 4, 1, 8},   //  4..7 : 128 x 32/48/64/80
+    {1, 2, 4, 1, 8}, {1, 3, 4, 1, 8},                                     //  8..9 :  64 x 32/48
+    {1, 2, 2, 2, 8}, {1, 3, 2, 2, 8},                                     // 10..11:  32 x 64/96
+    {1, 2, 1, 4, 8},                                                      // 12    :  16 x 128
+    {4, 2, 4, 1, 4}, {1, 2, 4, 1, 4},                                     // 13..14: 1-/2-channel audio input
 };
-static const int kNumConvVariants = sizeof(kConvVariants) / sizeof(kConvVariants[0]);
 
 static inline int conv_J(const ConvArgs& a) { return a.loader == LOADER_DEINT ? (a.KW + 1) / 2 : a.KW; }
 
-int conv_pick_variant(const ConvArgs& a) {
-    const int Ctot = a.C0 + a.C1;
-    if (Ctot <= 4) return 7;
-    if (a.Tout <= 24) return 6;
-    if (a.Tout <= 48) return 8;
-    if (a.Tout <= 160) return 5;
-    // wide-time variants: choose the cout tile that wastes the fewest padded columns
-    int best = 1, bestpad = 1 << 30;
-    for (int v = 4; v >= 0; --v) {
-        const int nt = kConvVariants[v].NW * 16;
-        const int padded = ((a.N + nt - 1) / nt) * nt;
-        if (padded < bestpad) { bestpad = padded; best = v; }
+static int pick_nw(int N, const int* cands, int ncand) {
+    // fewest padded columns; ties resolved by the order of `cands`
+    int best = cands[0], bestpad = 1 << 30;
+    for (int i = 0; i < ncand; ++i) {
+        const int nt = cands[i] * 16;
+        const int padded = ((N + nt - 1) / nt) * nt;
+        if (padded < bestpad) { bestpad = padded; best = cands[i]; }
     }
     return best;
+}
+
+int conv_pick_variant(const ConvArgs& a) {
+    const int Ctot = a.C0 + a.C1;
+    if (Ctot <= 4) return a.Tout > 64 ? 13 : 14;
+    if (a.Tout <= 16) return 12;
+    if (a.Tout <= 32) { const int c[2] = {3, 2}; return pick_nw(a.N, c, 2) == 3 ? 11 : 10; }
+    if (a.Tout <= 64) { const int c[2] = {3, 2}; return pick_nw(a.N, c, 2) == 3 ? 9 : 8; }
+    const int pad256 = ((a.Tout + 255) / 256) * 256, pad128 = ((a.Tout + 127) / 128) * 128;
+    const int base = (pad128 < pad256) ? 4 : 0;
+    const int c[4] = {3, 5, 4, 2};
+    const int nw = pick_nw(a.N, c, 4);
+    return base + (nw - 2);
 }
 
 static void conv_geom(const ConvArgs& a, int variant, int& TT, int& NT, int& J, int& XP, int& WP) {
@@ -292,55 +446,124 @@ double conv_flops(const ConvArgs& a) {
     return 2.0 * a.KW * (double)(a.C0 + a.C1) * a.N * (double)a.Tout * a.B;
 }
 
-template <int MT, int NW, int WT, int WN, int CK>
-static hipError_t conv_launch_t(const ConvArgs& a, int variant, hipStream_t s) {
+// split-K decision: (ksplit, chunks per split) from shapes only (deterministic)
+void conv_splitk(const ConvArgs& a, int variant, long long part_cap_floats, int& ksplit, int& cps) {
+    int TT, NT, J, XP, WP;
+    conv_geom(a, variant, TT, NT, J, XP, WP);
+    const int CK = kConvVariants[variant].CK;
+    const int CKC = a.loader == LOADER_DEINT ? CK / 2 : CK;
+    const int nchunks = (a.C0 + a.C1 + CKC - 1) / CKC;
+    const long long natural = (long long)((a.Tout + TT - 1) / TT) * ((a.N + NT - 1) / NT) * a.B;
+    ksplit = 1; cps = nchunks;
+    if (natural >= 512 || nchunks < 2 || part_cap_floats <= 0) return;
+    long long want = (1024 + natural - 1) / natural;
+    if (want > nchunks) want = nchunks;
+    const long long per = (long long)a.B * a.N * ((a.Tout + 3) & ~3);
+    if (want * per > part_cap_floats) want = part_cap_floats / per;
+    if (want < 2) return;
+    cps = (int)((nchunks + want - 1) / want);
+    ksplit = (nchunks + cps - 1) / cps;
+    if (ksplit < 2) { ksplit = 1; cps = nchunks; }
+}
+
+template <int MT, int NW, int WT, int WN, int CK, bool VECW>
+static hipError_t conv_launch_t(ConvArgs a, int variant, float* part, long long part_cap, hipStream_t s) {
     int TT, NT, J, XP, WP;
     conv_geom(a, variant, TT, NT, J, XP, WP);
     const int nTT = (a.Tout + TT - 1) / TT, nNT = (a.N + NT - 1) / NT;
     const size_t lds = conv_lds_bytes(a, variant);
-    auto kern = conv_mfma_kernel<MT, NW, WT, WN, CK>;
+    auto kern = conv_mfma_kernel<MT, NW, WT, WN, CK, VECW>;
     static size_t lds_allowed = 64 * 1024;
     if (lds > lds_allowed) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         lds_allowed = lds;
     }
-    const long long grid = (long long)nTT * nNT * a.B;
+    int ksplit, cps;
+    conv_splitk(a, variant, part != nullptr ? part_cap : 0, ksplit, cps);
+    a.cps = cps;
+    a.part = ksplit > 1 ? part : nullptr;
+    const long long grid = (long long)nTT * nNT * a.B * ksplit;
     if (grid <= 0) return hipSuccess;
     char nm[64];
-    snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d>", MT, NW, WT, WN, CK);
-    ProfScope ps(nm, conv_flops(a), s);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a, nTT, nNT, J, XP, WP);
+    snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %s>", MT, NW, WT, WN, CK, VECW ? "true" : "false");
+    {
+        ProfScope ps(nm, conv_flops(a), s);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a, nTT, nNT, J, XP, WP);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || ksplit == 1) return e;
+    const long long total = (long long)a.B * a.N * a.Tout;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, ksplit);
     return hipGetLastError();
 }
 
-hipError_t launch_conv(const ConvArgs& a, hipStream_t s) {
-    const int v = conv_pick_variant(a);
-    switch (v) {
-        case 0: return conv_launch_t<4, 2, 4, 1, 8>(a, v, s);
-        case 1: return conv_launch_t<4, 3, 4, 1, 8>(a, v, s);
-        case 2: return conv_launch_t<4, 4, 4, 1, 8>(a, v, s);
-        case 3: return conv_launch_t<4, 5, 4, 1, 8>(a, v, s);
-        case 4: return conv_launch_t<4, 6, 4, 1, 8>(a, v, s);
-        case 5: return conv_launch_t<2, 3, 2, 2, 8>(a, v, s);
-        case 6: return conv_launch_t<1, 2, 1, 4, 8>(a, v, s);
-        case 7: return conv_launch_t<4, 2, 4, 1, 4>(a, v, s);
-        default: return conv_launch_t<1, 3, 2, 2, 8>(a, v, s);
+// Vector (16-byte) paths need aligned bases / pitches; everything the plan allocates is.
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+hipError_t launch_conv(const ConvArgs& a_in, float* part, long long part_cap, hipStream_t s) {
+    ConvArgs a = a_in;
+    if (conv_J(a) > WUN_JMAX) return hipErrorInvalidValue;       // rejected at plan creation
+    const bool vecw = (a.N & 3) == 0 && aligned16(a.W);
+    bool vec = a.ostride == 1 && aligned16(a.dst0) && (a.obs0 & 3) == 0 && (a.opitch0 & 3) == 0 && (a.ooff0 & 3) == 0;
+    if (a.dst1 != nullptr)
+        vec = vec && aligned16(a.dst1) && (a.obs1 & 3) == 0 && (a.opitch1 & 3) == 0 && (a.ooff1 & 3) == 0;
+    if (a.msk0 != nullptr) vec = vec && aligned16(a.msk0);
+    if (a.msk1 != nullptr) vec = vec && aligned16(a.msk1);
+    if (a.dec != nullptr) vec = vec && (a.decpitch & 1) == 0 && (a.decbs & 1) == 0;
+    if (vec) a.flags |= F_VEC4;
+    int v = conv_pick_variant(a);
+    if (!vecw) {
+        // channel counts that are not multiples of 4 (non-shipped configs): scalar weight loads,
+        // restricted tile menu
+        const int Ctot = a.C0 + a.C1;
+        if (Ctot <= 4) v = a.Tout > 64 ? 13 : 14;
+        else v = a.Tout <= 16 ? 12 : (a.Tout <= 64 ? 9 : 1);
+        switch (v) {
+            case 1: return conv_launch_t<4, 3, 4, 1, 8, false>(a, v, part, part_cap, s);
+            case 9: return conv_launch_t<1, 3, 4, 1, 8, false>(a, v, part, part_cap, s);
+            case 12: return conv_launch_t<1, 2, 1, 4, 8, false>(a, v, part, part_cap, s);
+            case 13: return conv_launch_t<4, 2, 4, 1, 4, false>(a, v, part, part_cap, s);
+            default: return conv_launch_t<1, 2, 4, 1, 4, false>(a, v, part, part_cap, s);
+        }
     }
+#define WUN_CV(i, MT, NW, WT, WN, CK) case i: return conv_launch_t<MT, NW, WT, WN, CK, true>(a, v, part, part_cap, s);
+    switch (v) {
+        WUN_CV(0, 4, 2, 4, 1, 8) WUN_CV(1, 4, 3, 4, 1, 8) WUN_CV(2, 4, 4, 4, 1, 8) WUN_CV(3, 4, 5, 4, 1, 8)
+        WUN_CV(4, 2, 2, 4, 1, 8) WUN_CV(5, 2, 3, 4, 1, 8) WUN_CV(6, 2, 4, 4, 1, 8) WUN_CV(7, 2, 5, 4, 1, 8)
+        WUN_CV(8, 1, 2, 4, 1, 8) WUN_CV(9, 1, 3, 4, 1, 8)
+        WUN_CV(10, 1, 2, 2, 2, 8) WUN_CV(11, 1, 3, 2, 2, 8)
+        WUN_CV(12, 1, 2, 1, 4, 8)
+        WUN_CV(13, 4, 2, 4, 1, 4) WUN_CV(14, 1, 2, 4, 1, 4)
+        default: return hipErrorInvalidValue;
+    }
+#undef WUN_CV
 }
 
 // =====================================================================================
 // weight / bias gradient
 // =====================================================================================
+// D[(cin,tap) 16][cout 16] += A[(cin,tap)][q] * B[q][cout]; reduction over (batch, q) split
+// over workgroups ("units" of TK <= 128 output positions), partial sums to scratch, summed
+// in a fixed order by reduce_splits_*.  Row (cin,tap) of A is the input row `cin` read at
+// offset `tap`, so one staged input row serves all taps.  Staging is 16-byte global loads
+// into registers one unit ahead of the MFMAs (aligned vectors; the sub-vector shift
+// `delta` is folded into the LDS read offset), de-interleaved into even/odd planes for the
+// stride-2 convs.  An extra all-ones A row produces the bias gradient.
+#define WUN_WG_XIT 8      // float4 X loads per thread and unit (geometry guarantees it suffices)
+
 template <int MTW, int NW>
-__global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a, int nMG, int nNG, int TK,
-                                                         int XP, int ZP, int nChMax, int ONESP) {
+__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a, int nMG, int nNG, int TK,
+                                                         int XP, int ZP, int nChMax, int ONESP,
+                                                         int XW4) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int MG = 4 * MTW * 16;
     constexpr int NG = NW * 16;
+    constexpr int ZIT = (NG * 32 + 255) / 256;          // TK/4 <= 32 float4 per dz row
     const bool deint = (a.loader == LOADER_DEINT);
     const int planes = deint ? 2 : 1;
-    const int Jx = deint ? (a.KW + 1) / 2 : a.KW;      // halo width per plane
     float* Xs = lds + ONESP;
     float* Zs = Xs + nChMax * planes * XP;
 
@@ -361,6 +584,10 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a, int nMG, i
     if (cHi > Ctot - 1) cHi = Ctot - 1;
     const int nCh = cHi - cLo + 1;                     // may be <= 0 (bias-only group)
 
+    // (off - shift) mod 4 fixes the sub-vector shift of every unit (q0 is a multiple of 4)
+    const int delta0 = ((a.off0 - a.shift) % 4 + 4) % 4;
+    const int delta1 = ((a.off1 - a.shift) % 4 + 4) % 4;
+
     int rowoff[MTW];
     int nact = 0;                                      // wave-uniform count of live M tiles
 #pragma unroll
@@ -371,7 +598,8 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a, int nMG, i
         int off = 0;                                   // ones row
         if (r < Mtot) {
             const int c = r / a.KW, k = r - c * a.KW;
-            off = ONESP + (c - cLo) * planes * XP + (deint ? ((k & 1) * XP + (k >> 1)) : k);
+            const int kd = k + (c < a.C0 ? delta0 : delta1);
+            off = ONESP + (c - cLo) * planes * XP + (deint ? ((kd & 1) * XP + (kd >> 1)) : kd);
         }
         rowoff[mt] = off;
     }
@@ -383,46 +611,102 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a, int nMG, i
 #pragma unroll
         for (int n = 0; n < NW; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nunits = a.B * a.nQT;
-    int u1 = (split + 1) * a.units_per_split;
-    if (u1 > nunits) u1 = nunits;
-    for (int u = split * a.units_per_split; u < u1; ++u) {
-        const int b = u / a.nQT, qt = u % a.nQT;
+    f32x4 xreg[WUN_WG_XIT];
+    f32x4 zreg[ZIT];
+    const int TK4 = TK >> 2;
+    const float inv_xw4 = 1.0f / (float)XW4, inv_tk4 = 1.0f / (float)TK4;
+
+    // Buffers are in the plan's canonical layout: row pitch % 4 == 0, 16-byte aligned rows,
+    // off + Tin <= pitch.  Every vector is loaded from an in-row clamped position and masked
+    // by its virtual time, so the loads are branch-free.
+    auto load_unit = [&](int u) {
+        const int b = u / a.nQT, qt = u - b * a.nQT;
         const int q0 = qt * TK;
+        const int tb = (deint ? 2 * q0 : q0) - a.shift;
+        const float* base0 = a.src0 + (long long)b * a.bs0;
+        const float* base1 = (a.C1 > 0) ? a.src1 + (long long)b * a.bs1 : base0;
+#pragma unroll
+        for (int i = 0; i < WUN_WG_XIT; ++i) {
+            const int f = tid + i * 256;
+            const int row = (int)(((float)f + 0.5f) * inv_xw4);
+            const int c4 = f - row * XW4;
+            const int c = cLo + (row < nCh ? row : 0);
+            const bool s0 = c < a.C0;
+            const int off = s0 ? a.off0 : a.off1;
+            const int pitch = s0 ? a.pitch0 : a.pitch1;
+            const int e0 = ((tb + off) & ~3) + 4 * c4;           // element index in the row (multiple of 4)
+            int e0c = e0 < 0 ? 0 : e0;
+            if (e0c > pitch - 4) e0c = pitch - 4;
+            const int rel = (s0 ? c * a.pitch0 : (c - a.C0) * a.pitch1) + e0c;
+            f32x4 v = *reinterpret_cast<const f32x4*>((s0 ? base0 : base1) + rel);
+            const int t0 = e0 - off;                             // virtual time of element 0
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (row >= nCh || t0 + k < 0 || t0 + k >= a.Tin) v[k] = 0.f;
+            xreg[i] = v;
+        }
         int nq = a.Tq - q0; if (nq > TK) nq = TK;
-        const int nq4 = (nq + 3) & ~3;
-        __syncthreads();
-        // stage X rows (one wave per channel row, lanes along time)
-        for (int ci = wave; ci < nCh; ci += 4) {
-            const int c = cLo + ci;
-            const float* p = (c < a.C0)
-                ? a.src0 + (long long)b * a.bs0 + (long long)c * a.pitch0 + a.off0
-                : a.src1 + (long long)b * a.bs1 + (long long)(c - a.C0) * a.pitch1 + a.off1;
-            if (!deint) {
-                const int tbase = q0 - a.shift;
-                const int width = nq4 + a.KW - 1;
-                for (int x = lane; x < width; x += 64) {
-                    const int t = tbase + x;
-                    Xs[ci * XP + x] = (t >= 0 && t < a.Tin) ? p[t] : 0.f;
-                }
-            } else {
-                const int tbase = 2 * q0 - a.shift;
-                const int width = 2 * (nq4 + Jx - 1);
-                for (int e = lane; e < width; e += 64) {
-                    const int t = tbase + e;
-                    Xs[(ci * 2 + (e & 1)) * XP + (e >> 1)] = (t >= 0 && t < a.Tin) ? p[t] : 0.f;
+        const float* zb = a.dz + (long long)b * a.dzbs + q0;
+#pragma unroll
+        for (int i = 0; i < ZIT; ++i) {
+            const int f = tid + i * 256;
+            const int row = (int)(((float)f + 0.5f) * inv_tk4);
+            const int c4 = f - row * TK4;
+            int nn = ng * NG + row;
+            const bool rok = row < NG && nn < a.N;
+            if (!rok) nn = 0;
+            int qq = 4 * c4;
+            if (q0 + qq > a.dzpitch - 4) qq = a.dzpitch - 4 - q0;
+            f32x4 v = *reinterpret_cast<const f32x4*>(zb + (long long)nn * a.dzpitch + qq);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (!rok || 4 * c4 + k >= nq) v[k] = 0.f;
+            zreg[i] = v;
+        }
+    };
+    auto store_unit = [&]() {
+#pragma unroll
+        for (int i = 0; i < WUN_WG_XIT; ++i) {
+            const int f = tid + i * 256;
+            const int row = (int)(((float)f + 0.5f) * inv_xw4);
+            const int c4 = f - row * XW4;
+            if (row < nCh) {
+                if (!deint) {
+                    *reinterpret_cast<f32x4*>(&Xs[row * XP + 4 * c4]) = xreg[i];
+                } else {
+                    float* p0 = &Xs[(row * 2) * XP + 2 * c4];
+                    float* p1 = &Xs[(row * 2 + 1) * XP + 2 * c4];
+                    *reinterpret_cast<float2*>(p0) = make_float2(xreg[i][0], xreg[i][2]);
+                    *reinterpret_cast<float2*>(p1) = make_float2(xreg[i][1], xreg[i][3]);
                 }
             }
         }
-        // stage dZ rows
-        for (int n = wave; n < NG; n += 4) {
-            const int nn = ng * NG + n;
-            const float* p = a.dz + (long long)b * a.dzbs + (long long)nn * a.dzpitch + q0;
-            for (int q = lane; q < nq4; q += 64)
-                Zs[n * ZP + q] = (nn < a.N && q < nq) ? p[q] : 0.f;
+#pragma unroll
+        for (int i = 0; i < ZIT; ++i) {
+            const int f = tid + i * 256;
+            const int row = (int)(((float)f + 0.5f) * inv_tk4);
+            const int c4 = f - row * TK4;
+            if (row < NG) {
+                float* p = &Zs[row * ZP + 4 * c4];
+                *reinterpret_cast<float2*>(p) = make_float2(zreg[i][0], zreg[i][1]);
+                *reinterpret_cast<float2*>(p + 2) = make_float2(zreg[i][2], zreg[i][3]);
+            }
         }
+    };
+
+    const int nunits = a.B * a.nQT;
+    const int u0 = split * a.units_per_split;
+    int u1 = u0 + a.units_per_split;
+    if (u1 > nunits) u1 = nunits;
+    if (u0 < u1) load_unit(u0);
+    for (int u = u0; u < u1; ++u) {
+        const int qt = u % a.nQT;
+        int nq = a.Tq - qt * TK; if (nq > TK) nq = TK;
+        const int nsteps = (nq + 3) >> 2;
         __syncthreads();
-        const int nsteps = nq4 >> 2;
+        store_unit();
+        __syncthreads();
+        if (u + 1 < u1) load_unit(u + 1);
         for (int s = 0; s < nsteps; ++s) {
             float av[MTW], bv[NW];
 #pragma unroll
@@ -461,36 +745,45 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a, int nMG, i
     }
 }
 
-struct WgradGeom { int MTW, NW, nMG, nNG, TK, XP, ZP, nChMax, ONESP; size_t lds; };
+struct WgradGeom { int MTW, NW, nMG, nNG, TK, XP, ZP, nChMax, ONESP, XW4; size_t lds; };
 
 static WgradGeom wgrad_geom(const WgradArgs& a) {
     WgradGeom g;
     const int Ctot = a.C0 + a.C1;
     const int mtiles = (Ctot * a.KW + 1 + 15) / 16;
-    g.MTW = mtiles <= 4 ? 1 : (mtiles <= 8 ? 2 : 6);
     int bestnw = 3, bestpad = 1 << 30;
     for (int nw = 3; nw >= 1; --nw) {
         const int padded = ((a.N + nw * 16 - 1) / (nw * 16)) * nw * 16;
         if (padded < bestpad) { bestpad = padded; bestnw = nw; }
     }
     g.NW = bestnw;
-    const int MG = 4 * g.MTW * 16, NG = g.NW * 16;
-    g.nMG = (Ctot * a.KW + 1 + MG - 1) / MG;
-    g.nNG = (a.N + NG - 1) / NG;
     int tk = (a.Tq + 3) & ~3;
     if (tk > 128) tk = 128;
     if (tk < 4) tk = 4;
     g.TK = tk;
     const bool deint = a.loader == LOADER_DEINT;
     const int Jx = deint ? (a.KW + 1) / 2 : a.KW;
-    const int mod = deint ? 10 : (a.KW >= 9 ? 16 : (a.KW >= 5 ? 8 : (a.KW >= 3 ? 4 : 2)));
-    g.XP = fit_pitch(tk + Jx - 1, mod);
+    // float4 per staged input row: span of the unit + up to 3 elements of alignment slack
+    g.XW4 = deint ? (2 * (tk + Jx - 1) + 3 + 3) / 4 : (tk + a.KW - 1 + 3 + 3) / 4;
+    const int mod = deint ? 10 : (a.KW >= 9 ? 16 : (a.KW >= 5 ? 8 : 4));
+    g.XP = fit_pitch(deint ? 2 * g.XW4 : 4 * g.XW4, mod);
     g.ZP = fit_pitch(tk, 2);
-    int nch = (MG + a.KW - 2) / a.KW + 1;
-    if (nch > Ctot) nch = Ctot;
-    g.nChMax = nch;
+    // the M-group (rows of 4*MTW*16 (cin,tap) pairs) must stage within WUN_WG_XIT vectors/thread
+    int mtw = mtiles <= 4 ? 1 : (mtiles <= 8 ? 2 : 6);
+    for (;;) {
+        const int MG = 4 * mtw * 16;
+        int nch = (MG + a.KW - 2) / a.KW + 1;
+        if (nch > Ctot) nch = Ctot;
+        g.nChMax = nch;
+        if ((long long)nch * g.XW4 <= (long long)WUN_WG_XIT * 256 || mtw == 1) break;
+        mtw = mtw == 6 ? 4 : (mtw == 4 ? 2 : 1);
+    }
+    g.MTW = mtw;
+    const int MG = 4 * g.MTW * 16, NG = g.NW * 16;
+    g.nMG = (Ctot * a.KW + 1 + MG - 1) / MG;
+    g.nNG = (a.N + NG - 1) / NG;
     g.ONESP = (tk + 15) & ~15;
-    g.lds = sizeof(float) * ((size_t)g.ONESP + (size_t)nch * (deint ? 2 : 1) * g.XP + (size_t)NG * g.ZP);
+    g.lds = sizeof(float) * ((size_t)g.ONESP + (size_t)g.nChMax * (deint ? 2 : 1) * g.XP + (size_t)NG * g.ZP);
     return g;
 }
 
@@ -526,15 +819,21 @@ static hipError_t wgrad_launch_t(WgradArgs a, const WgradGeom& g, hipStream_t s)
     snprintf(nm, sizeof(nm), "wgrad_mfma_kernel<%d, %d>", MTW, NW);
     ProfScope ps(nm, 2.0 * a.KW * (double)(a.C0 + a.C1) * a.N * (double)a.Tq * a.B, s);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), g.lds, s, a, g.nMG, g.nNG, g.TK, g.XP,
-                       g.ZP, g.nChMax, g.ONESP);
+                       g.ZP, g.nChMax, g.ONESP, g.XW4);
     return hipGetLastError();
 }
 
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
+    // canonical layout required (the plan's buffers are; the single-op entry points repack)
+    if ((a.pitch0 & 3) || (a.bs0 & 3) || (reinterpret_cast<uintptr_t>(a.src0) & 15) || a.pitch0 < 4) return hipErrorInvalidValue;
+    if (a.C1 > 0 && ((a.pitch1 & 3) || (a.bs1 & 3) || (reinterpret_cast<uintptr_t>(a.src1) & 15) || a.pitch1 < 4)) return hipErrorInvalidValue;
+    if ((a.dzpitch & 3) || (a.dzbs & 3) || (reinterpret_cast<uintptr_t>(a.dz) & 15) || a.dzpitch < 4) return hipErrorInvalidValue;
     const WgradGeom g = wgrad_geom(a);
+    if ((long long)g.nChMax * g.XW4 > (long long)WUN_WG_XIT * 256) return hipErrorInvalidValue;
 #define WUN_WG(M, N) if (g.MTW == M && g.NW == N) return wgrad_launch_t<M, N>(a, g, s);
     WUN_WG(1, 1) WUN_WG(1, 2) WUN_WG(1, 3)
     WUN_WG(2, 1) WUN_WG(2, 2) WUN_WG(2, 3)
+    WUN_WG(4, 1) WUN_WG(4, 2) WUN_WG(4, 3)
     WUN_WG(6, 1) WUN_WG(6, 2) WUN_WG(6, 3)
 #undef WUN_WG
     return hipErrorInvalidValue;
@@ -551,8 +850,34 @@ __global__ void reduce_splits_kernel(const float* __restrict__ partial, long lon
     }
 }
 
+// many splits, few elements: 16 element lanes x 16 split lanes per block, fixed summation order
+__global__ __launch_bounds__(256) void reduce_splits_wide_kernel(const float* __restrict__ partial,
+                                                                 long long stride, int nsplit,
+                                                                 float* __restrict__ out, long long n) {
+    __shared__ float red[16][17];
+    const int ex = threadIdx.x & 15, y = threadIdx.x >> 4;
+    const long long e = (long long)blockIdx.x * 16 + ex;
+    float s = 0.f;
+    if (e < n)
+        for (int k = y; k < nsplit; k += 16) s += partial[(long long)k * stride + e];
+    red[y][ex] = s;
+    __syncthreads();
+    if (y == 0 && e < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][ex];
+        out[e] = t;
+    }
+}
+
 hipError_t launch_reduce(const float* partial, long long stride, int nsplit, float* out,
                          long long n, hipStream_t s) {
+    if (nsplit >= 8) {
+        const long long blocks = (n + 15) / 16;
+        hipLaunchKernelGGL(reduce_splits_wide_kernel, dim3((unsigned)blocks), dim3(256), 0, s, partial,
+                           stride, nsplit, out, n);
+        return hipGetLastError();
+    }
     long long blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;

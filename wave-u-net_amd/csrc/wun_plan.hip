@@ -38,6 +38,8 @@ static int check_config(const wun_config* c) {
     if (c->num_initial_filters < 1) return fail(WUN_ERR_INVALID, "num_initial_filters < 1");
     if (c->filter_size < 1 || c->merge_filter_size < 1 || c->output_filter_size < 1 || c->input_filter_size < 1)
         return fail(WUN_ERR_INVALID, "filter sizes must be >= 1");
+    if (c->filter_size > 15 || c->merge_filter_size > 15)
+        return fail(WUN_ERR_UNSUPPORTED, "filter_size / merge_filter_size > 15 not supported by the gfx950 kernels");
     if (c->upsampling != 0 && c->upsampling != 1) return fail(WUN_ERR_UNSUPPORTED, "upsampling must be linear|learned");
     if (c->output_type != 0 && c->output_type != 1) return fail(WUN_ERR_UNSUPPORTED, "output_type must be direct|difference");
     if (c->output_activation != 0 && c->output_activation != 1)
@@ -102,6 +104,7 @@ struct wun_plan {
     long long dpre_off = -1; int dp_pitch = 0;
     long long partial_off = -1, partial_floats = 0;
     long long loss_partial_off = -1;
+    long long conv_part_off = -1, conv_part_floats = 0;
     std::vector<WtDesc> wt;
     WtDesc* dev_wt = nullptr;
     int wt_max = 0;
@@ -253,6 +256,8 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
     p->dp_pitch = (p->Tout + 3) / 4 * 4;
     p->dpre_off = bump(w, (long long)p->Sh * B * C * p->dp_pitch);
     p->loss_partial_off = bump(w, 1024);
+    p->conv_part_floats = 16ll << 20;                       // split-K scratch (64 MiB)
+    p->conv_part_off = bump(w, p->conv_part_floats);
 
     // ---- transposed / tap-flipped weights for the input-gradient convs ----
     auto add_wt = [&](const ConvLayer& cl, int J, int k_last, int k_step) -> long long {
@@ -441,7 +446,7 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
             a.KW = Kd; a.N = a.N0 = d.cout; a.Tout = d.t_conv; a.flags = F_LRELU;
             set_dst0(a, ws, p->skip[i], 0, nullptr);
             a.dec = ws + p->dec[i].off; a.decbs = p->dec[i].bs; a.decpitch = p->dec[i].pitch;
-            HIP_TRY(launch_conv(a, s));
+            HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats, s));
         } else {
             // stride-2 conv straight into the decimated stream (odd outputs are never observed)
             ConvArgs a = conv_base(p);
@@ -450,14 +455,14 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
             a.Tin = d.t_in; a.shift = 0; a.W = params + cl.woff; a.bias = params + cl.boff;
             a.KW = Kd; a.N = a.N0 = d.cout; a.Tout = d.t_dec; a.flags = F_LRELU;
             set_dst0(a, ws, p->dec[i], 0, nullptr);
-            HIP_TRY(launch_conv(a, s));
+            HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats, s));
             // full-rate conv only over the window the skip connection crops (Utils.py:104-123)
             ConvArgs b = conv_base(p);
             set_src0(b, ws, *x, d.cs, d.cin);
             b.Tin = d.tc + Kd - 1; b.shift = 0; b.W = params + cl.woff; b.bias = params + cl.boff;
             b.KW = Kd; b.N = b.N0 = d.cout; b.Tout = d.tc; b.flags = F_LRELU;
             set_dst0(b, ws, p->skip[i], 0, nullptr);
-            HIP_TRY(launch_conv(b, s));
+            HIP_TRY(launch_conv(b, ws + p->conv_part_off, p->conv_part_floats, s));
         }
         x = &p->dec[i];
     }
@@ -467,7 +472,7 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
         a.Tin = p->t_b_in; a.shift = padD; a.W = params + p->bott.woff; a.bias = params + p->bott.boff;
         a.KW = Kd; a.N = a.N0 = p->c_b; a.Tout = p->t_b; a.flags = F_LRELU;
         set_dst0(a, ws, p->bott_out, 0, nullptr);
-        HIP_TRY(launch_conv(a, s));
+        HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats, s));
     }
     const Buf* cur = &p->bott_out;
     for (int j = 0; j < L; ++j) {                                   // :107-125
@@ -485,7 +490,7 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
         a.Tin = u.t_up; a.shift = padU; a.W = params + p->up[j].woff; a.bias = params + p->up[j].boff;
         a.KW = Ku; a.N = a.N0 = u.cout; a.Tout = u.t_conv; a.flags = F_LRELU;
         set_dst0(a, ws, p->upo[j], 0, nullptr);
-        HIP_TRY(launch_conv(a, s));
+        HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats, s));
         cur = &p->upo[j];
     }
     HeadArgs h = head_args(p, params, ws, outputs, training);
@@ -575,7 +580,7 @@ extern "C" int wun_loss_backward(const wun_plan* p, const float* params, const f
             a.N = u.c_skip + u.c_cur; a.N0 = u.c_skip; a.Tout = u.t_up;
             set_dst0(a, ws, p->dz_skip[i], 0, &p->skip[i]);
             set_dst1(a, ws, p->d_ups[j], 0, nullptr);
-            HIP_TRY(launch_conv(a, s));
+            HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats, s));
         }
         {
             const Buf& prev = (j == 0) ? p->bott_out : p->upo[j - 1];
@@ -609,7 +614,7 @@ extern "C" int wun_loss_backward(const wun_plan* p, const float* params, const f
         } else {
             set_dst0(a, ws, p->dz_dec[L - 1], 0, &p->dec[L - 1]);
         }
-        HIP_TRY(launch_conv(a, s));
+        HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats, s));
     }
 
     // ---- down path ----
@@ -630,7 +635,7 @@ extern "C" int wun_loss_backward(const wun_plan* p, const float* params, const f
                 a.N = a.N0 = d.cin; a.Tout = d.t_in;
                 set_dst0(a, ws, p->dz_skip[i - 1], 0, &p->skip[i - 1]);
                 a.ostride = 2; a.flags = F_ACCUM;
-                HIP_TRY(launch_conv(a, s));
+                HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats, s));
             }
         } else {
             WgradArgs w[2];
@@ -651,7 +656,7 @@ extern "C" int wun_loss_backward(const wun_plan* p, const float* params, const f
                     a.N = a.N0 = d.cin; a.Tout = (d.t_in - ph + 1) / 2;
                     set_dst0(a, ws, p->dz_dec[i - 1], ph, &p->dec[i - 1]);
                     a.ostride = 2;
-                    HIP_TRY(launch_conv(a, s));
+                    HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats, s));
                 }
                 ConvArgs a = conv_base(p);
                 set_src0(a, ws, p->dz_skip[i], 0, d.cout);
@@ -659,7 +664,7 @@ extern "C" int wun_loss_backward(const wun_plan* p, const float* params, const f
                 a.N = a.N0 = d.cin; a.Tout = d.tc + Kd - 1;
                 set_dst0(a, ws, p->dz_dec[i - 1], d.cs, &p->dec[i - 1]);
                 a.flags = F_ACCUM;
-                HIP_TRY(launch_conv(a, s));
+                HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats, s));
             }
         }
     }
@@ -680,6 +685,17 @@ extern "C" int wun_adam_step(const wun_plan* p, float* params, const float* grad
 // ---------------------------------------------------------------------------------------
 // single operators
 // ---------------------------------------------------------------------------------------
+// the single-operator entry points use a lazily allocated split-K scratch of their own
+static const long long kOpScratchFloats = 8ll << 20;
+static float* op_scratch() {
+    static float* buf = nullptr;
+    if (!buf && hipMalloc((void**)&buf, kOpScratchFloats * sizeof(float)) != hipSuccess) {
+        buf = nullptr;
+        (void)hipGetLastError();
+    }
+    return buf;
+}
+
 static void op_src(ConvArgs& a, const float* x, int C, int T) {
     const int pitch = T;
     a.src0 = x; a.bs0 = (long long)C * pitch; a.pitch0 = pitch; a.off0 = 0; a.C0 = C;
@@ -698,27 +714,31 @@ extern "C" int wun_op_conv1d(const float* x, const float* w, const float* bias, 
     a.Tin = t_in; a.shift = pad_left; a.W = w; a.bias = bias; a.KW = k; a.N = a.N0 = cout; a.Tout = t_out;
     a.flags = lrelu ? F_LRELU : 0;
     a.dst0 = y; a.obs0 = (long long)cout * t_out; a.opitch0 = t_out;
-    HIP_TRY(launch_conv(a, (hipStream_t)stream));
+    HIP_TRY(launch_conv(a, op_scratch(), kOpScratchFloats, (hipStream_t)stream));
     return WUN_OK;
 }
 
 static WgradArgs op_wgrad_args(const float* x, const float* dz, int batch, int cin, int cout, int k, int t_in,
-                               int t_out, int stride, int pad_left) {
+                               int t_out, int stride, int pad_left, int xp, int zp) {
     WgradArgs w;
     memset(&w, 0, sizeof(w));
     w.B = batch; w.loader = stride == 2 ? LOADER_DEINT : LOADER_DIRECT;
-    w.src0 = x; w.bs0 = (long long)cin * t_in; w.pitch0 = t_in; w.C0 = cin;
+    w.src0 = x; w.bs0 = (long long)cin * xp; w.pitch0 = xp; w.C0 = cin;
     w.Tin = t_in; w.shift = pad_left; w.KW = k;
-    w.dz = dz; w.dzbs = (long long)cout * t_out; w.dzpitch = t_out; w.N = cout; w.Tq = t_out;
+    w.dz = dz; w.dzbs = (long long)cout * zp; w.dzpitch = zp; w.N = cout; w.Tq = t_out;
     return w;
 }
 
+static inline int pad4(int t) { return (t + 3) / 4 * 4; }
+
 extern "C" int64_t wun_op_conv1d_wgrad_scratch(int batch, int cin, int cout, int k, int t_out) {
-    // worst case over both loaders
+    // split partials (worst case over both loaders) + repacked copies of x (t_in <= 2*t_out + k) and dz
     WgradArgs a = wgrad_shape_only(batch, cin, 0, k, LOADER_DIRECT, cout, t_out);
     WgradArgs b = wgrad_shape_only(batch, cin, 0, k, LOADER_DEINT, cout, t_out);
     const long long ns = std::max(wgrad_pick_nsplit(a), wgrad_pick_nsplit(b));
-    return ns * ((long long)k * cin * cout + cout);
+    const long long tin_max = 2ll * t_out + k + 8;
+    return ns * ((long long)k * cin * cout + cout) + (long long)batch * cin * pad4((int)tin_max) +
+           (long long)batch * cout * pad4(t_out) + 256;
 }
 
 extern "C" int wun_op_conv1d_wgrad(const float* x, const float* dz, float* dw, float* db, float* scratch,
@@ -726,14 +746,25 @@ extern "C" int wun_op_conv1d_wgrad(const float* x, const float* dz, float* dw, f
                                    int pad_left, void* stream) {
     if (!x || !dz || !dw || !db || !scratch) return fail(WUN_ERR_INVALID, "null argument");
     if (stride != 1 && stride != 2) return fail(WUN_ERR_UNSUPPORTED, "stride must be 1 or 2");
+    if (t_in > 2ll * t_out + k + 8) return fail(WUN_ERR_INVALID, "t_in larger than the conv can consume");
     hipStream_t s = (hipStream_t)stream;
-    WgradArgs w = op_wgrad_args(x, dz, batch, cin, cout, k, t_in, t_out, stride, pad_left);
+    // repack x / dz into the canonical 4-padded row layout the kernels use
+    const int xp = pad4(t_in), zp = pad4(t_out);
+    float* xs = scratch;                                   // 64-float aligned by construction below
+    xs = (float*)(((uintptr_t)xs + 255) & ~(uintptr_t)255);
+    float* zs = xs + (long long)batch * cin * xp;
+    float* part = zs + (long long)batch * cout * zp;
+    HIP_TRY(hipMemcpy2DAsync(xs, (size_t)xp * 4, x, (size_t)t_in * 4, (size_t)t_in * 4, (size_t)batch * cin,
+                             hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpy2DAsync(zs, (size_t)zp * 4, dz, (size_t)t_out * 4, (size_t)t_out * 4, (size_t)batch * cout,
+                             hipMemcpyDeviceToDevice, s));
+    WgradArgs w = op_wgrad_args(xs, zs, batch, cin, cout, k, t_in, t_out, stride, pad_left, xp, zp);
     w.nsplit = wgrad_pick_nsplit(w);
     const long long blk = (long long)k * cin * cout + cout;
-    w.out = scratch; w.split_stride = blk;
+    w.out = part; w.split_stride = blk;
     HIP_TRY(launch_wgrad(w, s));
-    HIP_TRY(launch_reduce(scratch, blk, w.nsplit, dw, (long long)k * cin * cout, s));
-    HIP_TRY(launch_reduce(scratch + (long long)k * cin * cout, blk, w.nsplit, db, cout, s));
+    HIP_TRY(launch_reduce(part, blk, w.nsplit, dw, (long long)k * cin * cout, s));
+    HIP_TRY(launch_reduce(part + (long long)k * cin * cout, blk, w.nsplit, db, cout, s));
     return WUN_OK;
 }
 
@@ -752,7 +783,7 @@ extern "C" int wun_op_conv1d_dgrad(const float* dz, const float* w, float* dx, f
         op_src(a, dz, cout, t_out);
         a.Tin = t_out; a.shift = k - 1 - pad_left; a.W = wt_scratch; a.KW = k; a.N = a.N0 = cin; a.Tout = t_in;
         a.dst0 = dx; a.obs0 = (long long)cin * t_in; a.opitch0 = t_in;
-        HIP_TRY(launch_conv(a, s));
+        HIP_TRY(launch_conv(a, op_scratch(), kOpScratchFloats, s));
     } else {
         if (pad_left != 0) return fail(WUN_ERR_UNSUPPORTED, "stride-2 dgrad supports pad_left == 0 only");
         for (int ph = 0; ph < 2; ++ph) {
@@ -767,7 +798,7 @@ extern "C" int wun_op_conv1d_dgrad(const float* dz, const float* w, float* dx, f
             op_src(a, dz, cout, t_out);
             a.Tin = t_out; a.KW = Jp; a.shift = Jp - 1; a.W = wt; a.N = a.N0 = cin; a.Tout = (t_in - ph + 1) / 2;
             a.dst0 = dx; a.obs0 = (long long)cin * t_in; a.opitch0 = t_in; a.ooff0 = ph;
-            HIP_TRY(launch_conv(a, s));
+            HIP_TRY(launch_conv(a, op_scratch(), kOpScratchFloats, s));
         }
     }
     return WUN_OK;
