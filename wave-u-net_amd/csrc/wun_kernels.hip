@@ -21,6 +21,7 @@
 #include "wun_internal.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <string>
@@ -162,117 +163,159 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
 
     float xreg[XIT];
     f32x4 wreg[WIT];          // VECW: one 16-byte load each; else 4 scalar loads each
+    unsigned xmask = 0, wmask = 0;   // validity bits of the chunk held in xreg / wreg
 
-    // ---- global -> registers for one chunk ----
+    // ---- chunk-invariant staging state, computed once: clamped time offsets + validity of the
+    // input window elements this thread stages, element offsets + validity of its weight
+    // vectors.  Per chunk only a uniform base (c0) changes. ----
+    int xt[XIT];
+    unsigned xmask_s = 0, wmask_s = 0;
+    const int xrow = deint ? tid / TPC : tid / TPR;       // LDS row (DIRECT) / channel (DEINT) staged by this thread
+    {
+        const int lr = deint ? tid % TPC : tid % TPR;
+        const int stride_i = deint ? TPC : TPR;
+        const int lim = deint ? 2 * UW : UW;
+        const int tbase = (deint ? 2 * q0 : q0) - a.shift;
+#pragma unroll
+        for (int i = 0; i < XIT; ++i) {
+            const int u = lr + i * stride_i;
+            const int t = tbase + u;
+            const bool ok = u < lim && t >= 0 && t < a.Tin;
+            int tc = t < 0 ? 0 : t;
+            if (tc > a.Tin - 1) tc = a.Tin - 1;
+            xt[i] = tc;
+            xmask_s |= (ok ? 1u : 0u) << i;
+        }
+    }
+    int wofs[WIT];            // element offset of this thread's i-th weight vector for channel chunk 0
+    int wr[WIT];              // channel index within the chunk (for the channel-tail mask)
+    const int nwvec = J * CK * NT4;                       // weight vectors per chunk (uniform)
+#pragma unroll
+    for (int i = 0; i < WIT; ++i) {
+        const int f = tid + i * 256;
+        const int row = f / NT4, c4 = f % NT4;
+        const int j = row / CK, r = row % CK;
+        int k, cch;
+        if (!deint) { k = j; cch = r; }
+        else { k = 2 * j + r / CH; cch = r % CH; }
+        const bool ok = f < nwvec && k < a.KW && n0 + c4 * 4 < a.N;
+        wofs[i] = ok ? (k * Ctot + cch) * a.N + n0 + c4 * 4 : 0;
+        wr[i] = cch;
+        wmask_s |= (ok ? 1u : 0u) << i;
+    }
+
+    // ---- global -> registers for one chunk.  Loads are unconditional (clamped addresses);
+    // the zero fill is applied when the registers are written to LDS, so nothing here
+    // waits for the loads and they stay in flight during the MFMAs of the previous chunk ----
     auto load_chunk = [&](int chunk) {
         const int c0 = chunk * CKC;
-        if (!deint) {
-            const int r = tid / TPR, lr = tid % TPR;
-            const int c = c0 + r;
+        {
+            const int c = c0 + xrow;
             const bool cok = c < Ctot;
             const float* p = (!cok || c < a.C0) ? src0b + (long long)(cok ? c : 0) * a.pitch0
                                                 : src1b + (long long)(c - a.C0) * a.pitch1;
-            const int tbase = q0 - a.shift;
+            const int nx = deint ? XIT_I : XIT_D;
 #pragma unroll
-            for (int i = 0; i < XIT_D; ++i) {
-                const int u = lr + i * TPR;
-                const int t = tbase + u;
-                const bool ok = cok && u < UW && t >= 0 && t < a.Tin;
-                int tc = t < 0 ? 0 : t;
-                if (tc > a.Tin - 1) tc = a.Tin - 1;
-                const float v = p[tc];
-                xreg[i] = ok ? v : 0.f;
-            }
-        } else {
-            const int cc = tid / TPC, le = tid % TPC;
-            const int c = c0 + cc;
-            const bool cok = c < Ctot;
-            const float* p = (!cok || c < a.C0) ? src0b + (long long)(cok ? c : 0) * a.pitch0
-                                                : src1b + (long long)(c - a.C0) * a.pitch1;
-            const int tbase = 2 * q0 - a.shift;
-#pragma unroll
-            for (int i = 0; i < XIT_I; ++i) {
-                const int e = le + i * TPC;
-                const int t = tbase + e;
-                const bool ok = cok && e < 2 * UW && t >= 0 && t < a.Tin;
-                int tc = t < 0 ? 0 : t;
-                if (tc > a.Tin - 1) tc = a.Tin - 1;
-                const float v = p[tc];
-                xreg[i] = ok ? v : 0.f;
-            }
+            for (int i = 0; i < XIT; ++i)
+                if (i < nx) xreg[i] = p[xt[i]];
+            xmask = cok ? xmask_s : 0u;
         }
+        const bool tail = c0 + CKC > Ctot;                // uniform; only the last chunk of odd configs
+        const float* wc = a.W + (long long)c0 * a.N;      // uniform base of this chunk's weight rows
+        wmask = wmask_s;
 #pragma unroll
         for (int i = 0; i < WIT; ++i) {
-            const int f = tid + i * 256;
-            const int row = f / NT4, c4 = f % NT4;
-            const int j = row / CK, r = row % CK;
-            int k, c;
-            if (!deint) { k = j; c = c0 + r; }
-            else { k = 2 * j + r / CH; c = c0 + r % CH; }
-            const bool rok = row < J * CK && c < Ctot && k < a.KW;
-            if constexpr (VECW) {
-                const bool ok = rok && n0 + c4 * 4 < a.N;
-                const float* wp = a.W + (ok ? ((long long)k * Ctot + c) * a.N + n0 + c4 * 4 : 0);
-                const f32x4 v = *reinterpret_cast<const f32x4*>(wp);
-                wreg[i] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
-            } else {
-                const float* wrow = a.W + (rok ? ((long long)k * Ctot + c) * a.N : 0);
+            if (i * 256 < nwvec) {                        // uniform: exact trip count for this J
+                const bool cok = !tail || c0 + wr[i] < Ctot;
+                const float* wp = cok ? wc + wofs[i] : a.W;
+                if constexpr (VECW) {
+                    wreg[i] = *reinterpret_cast<const f32x4*>(wp);
+                } else {
+                    const int f = tid + i * 256;
+                    const int c4 = f % NT4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int col = n0 + c4 * 4 + e;
-                    const bool ok = rok && col < a.N;
-                    const float v = wrow[ok ? col : 0];
-                    wreg[i][e] = ok ? v : 0.f;
+                    for (int e = 0; e < 4; ++e) {
+                        const bool eok = n0 + c4 * 4 + e < a.N;
+                        wreg[i][e] = eok ? wp[e] : 0.f;
+                    }
                 }
+                if (!cok) wmask &= ~(1u << i);
             }
         }
     };
-    // ---- registers -> LDS ----
+    // ---- registers -> LDS (zero fill applied here) ----
     auto store_chunk = [&]() {
         if (!deint) {
-            const int r = tid / TPR, lr = tid % TPR;
+            const int lr = tid % TPR;
+            float* xd = Xs + xrow * XP + lr;
 #pragma unroll
-            for (int i = 0; i < XIT_D; ++i) {
-                const int u = lr + i * TPR;
-                if (u < UW) Xs[r * XP + u] = xreg[i];
-            }
+            for (int i = 0; i < XIT_D; ++i)
+                if (lr + i * TPR < UW) xd[i * TPR] = ((xmask >> i) & 1u) ? xreg[i] : 0.f;
         } else {
-            const int cc = tid / TPC, le = tid % TPC;
+            const int le = tid % TPC;
+            float* xd = Xs + ((le & 1) * CH + xrow) * XP + (le >> 1);
 #pragma unroll
-            for (int i = 0; i < XIT_I; ++i) {
-                const int e = le + i * TPC;
-                if (e < 2 * UW) Xs[((e & 1) * CH + cc) * XP + (e >> 1)] = xreg[i];
-            }
+            for (int i = 0; i < XIT_I; ++i)
+                if (le + i * TPC < 2 * UW) xd[i * (TPC / 2)] = ((xmask >> i) & 1u) ? xreg[i] : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < WIT; ++i) {
-            const int f = tid + i * 256;
-            const int row = f / NT4, c4 = f % NT4;
-            if (row < J * CK) *reinterpret_cast<f32x4*>(&Ws[row * WP + c4 * 4]) = wreg[i];
+            if (i * 256 < nwvec) {
+                const int f = tid + i * 256;
+                const int row = f / NT4, c4 = f % NT4;
+                if (f < nwvec)
+                    *reinterpret_cast<f32x4*>(&Ws[row * WP + c4 * 4]) =
+                        ((wmask >> i) & 1u) ? wreg[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
         }
     };
 
-    if (ch_lo < ch_hi) load_chunk(ch_lo);
+#ifdef WUN_ABLATION
+    const bool ab_noload = a.flags & 256, ab_nostore = a.flags & 512, ab_nomfma = a.flags & 1024,
+               ab_noepi = a.flags & 2048, ab_nobar = a.flags & 4096;
+#else
+    constexpr bool ab_noload = false, ab_nostore = false, ab_nomfma = false, ab_noepi = false, ab_nobar = false;
+#endif
+    if (ch_lo < ch_hi && !ab_noload) load_chunk(ch_lo);
     for (int chunk = ch_lo; chunk < ch_hi; ++chunk) {
-        __syncthreads();                 // every wave is done reading the previous chunk
-        store_chunk();
-        __syncthreads();
-        if (chunk + 1 < ch_hi) load_chunk(chunk + 1);   // in flight during the MFMAs below
-        for (int j = 0; j < J; ++j) {
-            const float* xa = Xs + lg * XP + wt0 + li + j;
-            const float* wb = Ws + (j * CK + lg) * WP + wn0 + li;
+        if (!ab_nobar) __syncthreads();                 // every wave is done reading the previous chunk
+        if (!ab_nostore) store_chunk();
+        if (!ab_nobar) __syncthreads();
+        if (chunk + 1 < ch_hi && !ab_noload) load_chunk(chunk + 1);   // in flight during the MFMAs below
+        if (!ab_nomfma) {
+            // flat k-steps s = j*KS + ks (4 LDS rows each); operands of step s+1 are read from
+            // LDS while the MFMAs of step s issue (double-buffered registers)
+            constexpr int KS = CK / 4;
+            int nsteps = J * KS;
+            if (deint && CK == 8 && (a.KW & 1)) nsteps -= 1;       // the odd phase has no tap KW
+            const float* xb = Xs + lg * XP + wt0 + li;
+            const float* wbp = Ws + lg * WP + wn0 + li;
+            float a0[MT], b0[NW], a1[MT], b1[NW];
+            auto ldop = [&](int st, float (&av)[MT], float (&bv)[NW]) {
+                const int j = st / KS, ks = st % KS;
+                const float* xa = xb + j + ks * 4 * XP;
+                const float* wb = wbp + (j * CK + ks * 4) * WP;
 #pragma unroll
-            for (int ks = 0; ks < CK / 4; ++ks) {
-                if (deint && CK == 8 && ks == 1 && 2 * j + 1 >= a.KW) continue;  // odd phase has no such tap
-                float av[MT], bv[NW];
+                for (int m = 0; m < MT; ++m) av[m] = xa[m * 16];
 #pragma unroll
-                for (int m = 0; m < MT; ++m) av[m] = xa[ks * 4 * XP + m * 16];
-#pragma unroll
-                for (int n = 0; n < NW; ++n) bv[n] = wb[ks * 4 * WP + n * 16];
+                for (int n = 0; n < NW; ++n) bv[n] = wb[n * 16];
+            };
+            auto mm = [&](const float (&av)[MT], const float (&bv)[NW]) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int n = 0; n < NW; ++n) acc[m][n] = mfma16(av[m], bv[n], acc[m][n]);
+            };
+            if (nsteps > 0) {
+                ldop(0, a0, b0);
+                int st = 0;
+                for (; st + 1 < nsteps; st += 2) {
+                    ldop(st + 1, a1, b1);
+                    mm(a0, b0);
+                    if (st + 2 < nsteps) ldop(st + 2, a0, b0);
+                    mm(a1, b1);
+                }
+                if (nsteps & 1) mm(a0, b0);
             }
         }
     }
@@ -298,6 +341,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
     const bool lrelu = (a.flags & F_LRELU) != 0;
     const bool accum = (a.flags & F_ACCUM) != 0;
     const bool vec = (a.flags & F_VEC4) != 0;
+    if (ab_noepi && acc[0][0][0] != 12345.678f) return;
 #pragma unroll
     for (int n = 0; n < NW; ++n) {
         const int ncol = n0 + wn0 + n * 16 + li;
@@ -514,7 +558,14 @@ hipError_t launch_conv(const ConvArgs& a_in, float* part, long long part_cap, hi
     if (a.msk1 != nullptr) vec = vec && aligned16(a.msk1);
     if (a.dec != nullptr) vec = vec && (a.decpitch & 1) == 0 && (a.decbs & 1) == 0;
     if (vec) a.flags |= F_VEC4;
+#ifdef WUN_ABLATION
+    if (const char* e = getenv("WUN_ABLATE")) a.flags |= atoi(e) << 8;
+    if (const char* e = getenv("WUN_NOVEC")) if (atoi(e)) a.flags &= ~F_VEC4;
+#endif
     int v = conv_pick_variant(a);
+#ifdef WUN_ABLATION
+    if (const char* e = getenv("WUN_VARIANT")) v = atoi(e);
+#endif
     if (!vecw) {
         // channel counts that are not multiples of 4 (non-shipped configs): scalar weight loads,
         // restricted tile menu
@@ -617,8 +668,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a, int nMG
     const float inv_xw4 = 1.0f / (float)XW4, inv_tk4 = 1.0f / (float)TK4;
 
     // Buffers are in the plan's canonical layout: row pitch % 4 == 0, 16-byte aligned rows,
-    // off + Tin <= pitch.  Every vector is loaded from an in-row clamped position and masked
-    // by its virtual time, so the loads are branch-free.
+    // off + Tin <= pitch.  Every vector is loaded from an in-row clamped position; the zero
+    // fill (virtual time outside [0, Tin), rows beyond the group) is applied when the
+    // registers are written to LDS, so the loads stay in flight during the previous unit.
     auto load_unit = [&](int u) {
         const int b = u / a.nQT, qt = u - b * a.nQT;
         const int q0 = qt * TK;
@@ -638,14 +690,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a, int nMG
             int e0c = e0 < 0 ? 0 : e0;
             if (e0c > pitch - 4) e0c = pitch - 4;
             const int rel = (s0 ? c * a.pitch0 : (c - a.C0) * a.pitch1) + e0c;
-            f32x4 v = *reinterpret_cast<const f32x4*>((s0 ? base0 : base1) + rel);
-            const int t0 = e0 - off;                             // virtual time of element 0
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (row >= nCh || t0 + k < 0 || t0 + k >= a.Tin) v[k] = 0.f;
-            xreg[i] = v;
+            xreg[i] = *reinterpret_cast<const f32x4*>((s0 ? base0 : base1) + rel);
         }
-        int nq = a.Tq - q0; if (nq > TK) nq = TK;
         const float* zb = a.dz + (long long)b * a.dzbs + q0;
 #pragma unroll
         for (int i = 0; i < ZIT; ++i) {
@@ -653,31 +699,37 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a, int nMG
             const int row = (int)(((float)f + 0.5f) * inv_tk4);
             const int c4 = f - row * TK4;
             int nn = ng * NG + row;
-            const bool rok = row < NG && nn < a.N;
-            if (!rok) nn = 0;
+            if (!(row < NG && nn < a.N)) nn = 0;
             int qq = 4 * c4;
             if (q0 + qq > a.dzpitch - 4) qq = a.dzpitch - 4 - q0;
-            f32x4 v = *reinterpret_cast<const f32x4*>(zb + (long long)nn * a.dzpitch + qq);
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (!rok || 4 * c4 + k >= nq) v[k] = 0.f;
-            zreg[i] = v;
+            zreg[i] = *reinterpret_cast<const f32x4*>(zb + (long long)nn * a.dzpitch + qq);
         }
     };
-    auto store_unit = [&]() {
+    auto store_unit = [&](int u) {
+        const int b = u / a.nQT, qt = u - b * a.nQT;
+        const int q0 = qt * TK;
+        const int tb = (deint ? 2 * q0 : q0) - a.shift;
+        int nq = a.Tq - q0; if (nq > TK) nq = TK;
 #pragma unroll
         for (int i = 0; i < WUN_WG_XIT; ++i) {
             const int f = tid + i * 256;
             const int row = (int)(((float)f + 0.5f) * inv_xw4);
             const int c4 = f - row * XW4;
             if (row < nCh) {
+                const int c = cLo + row;
+                const int off = (c < a.C0) ? a.off0 : a.off1;
+                const int t0 = ((tb + off) & ~3) + 4 * c4 - off;     // virtual time of element 0
+                f32x4 v = xreg[i];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (t0 + k < 0 || t0 + k >= a.Tin) v[k] = 0.f;
                 if (!deint) {
-                    *reinterpret_cast<f32x4*>(&Xs[row * XP + 4 * c4]) = xreg[i];
+                    *reinterpret_cast<f32x4*>(&Xs[row * XP + 4 * c4]) = v;
                 } else {
                     float* p0 = &Xs[(row * 2) * XP + 2 * c4];
                     float* p1 = &Xs[(row * 2 + 1) * XP + 2 * c4];
-                    *reinterpret_cast<float2*>(p0) = make_float2(xreg[i][0], xreg[i][2]);
-                    *reinterpret_cast<float2*>(p1) = make_float2(xreg[i][1], xreg[i][3]);
+                    *reinterpret_cast<float2*>(p0) = make_float2(v[0], v[2]);
+                    *reinterpret_cast<float2*>(p1) = make_float2(v[1], v[3]);
                 }
             }
         }
@@ -687,9 +739,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a, int nMG
             const int row = (int)(((float)f + 0.5f) * inv_tk4);
             const int c4 = f - row * TK4;
             if (row < NG) {
+                const bool rok = ng * NG + row < a.N;
+                f32x4 v = zreg[i];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (!rok || 4 * c4 + k >= nq) v[k] = 0.f;
                 float* p = &Zs[row * ZP + 4 * c4];
-                *reinterpret_cast<float2*>(p) = make_float2(zreg[i][0], zreg[i][1]);
-                *reinterpret_cast<float2*>(p + 2) = make_float2(zreg[i][2], zreg[i][3]);
+                *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+                *reinterpret_cast<float2*>(p + 2) = make_float2(v[2], v[3]);
             }
         }
     };
@@ -704,22 +761,35 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a, int nMG
         int nq = a.Tq - qt * TK; if (nq > TK) nq = TK;
         const int nsteps = (nq + 3) >> 2;
         __syncthreads();
-        store_unit();
+        store_unit(u);
         __syncthreads();
         if (u + 1 < u1) load_unit(u + 1);
-        for (int s = 0; s < nsteps; ++s) {
-            float av[MTW], bv[NW];
+        {
+            float a0[MTW], b0[NW], a1[MTW], b1[NW];
+            auto ldop = [&](int st, float (&av)[MTW], float (&bv)[NW]) {
 #pragma unroll
-            for (int mt = 0; mt < MTW; ++mt) av[mt] = lds[rowoff[mt] + 4 * s + lg];
+                for (int mt = 0; mt < MTW; ++mt) av[mt] = lds[rowoff[mt] + 4 * st + lg];
 #pragma unroll
-            for (int n = 0; n < NW; ++n) bv[n] = Zs[(n * 16 + li) * ZP + 4 * s + lg];
+                for (int n = 0; n < NW; ++n) bv[n] = Zs[(n * 16 + li) * ZP + 4 * st + lg];
+            };
+            auto mm = [&](const float (&av)[MTW], const float (&bv)[NW]) {
 #pragma unroll
-            for (int mt = 0; mt < MTW; ++mt) {
-                if (mt < nact) {
+                for (int mt = 0; mt < MTW; ++mt) {
+                    if (mt < nact) {
 #pragma unroll
-                    for (int n = 0; n < NW; ++n) acc[mt][n] = mfma16(av[mt], bv[n], acc[mt][n]);
+                        for (int n = 0; n < NW; ++n) acc[mt][n] = mfma16(av[mt], bv[n], acc[mt][n]);
+                    }
                 }
+            };
+            ldop(0, a0, b0);
+            int st = 0;
+            for (; st + 1 < nsteps; st += 2) {
+                ldop(st + 1, a1, b1);
+                mm(a0, b0);
+                if (st + 2 < nsteps) ldop(st + 2, a0, b0);
+                mm(a1, b1);
             }
+            if (nsteps & 1) mm(a0, b0);
         }
     }
 
