@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwun.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("WUN_LIB", "libwun.so"))
 
 
 class WunConfig(C.Structure):

@@ -10,7 +10,7 @@ namespace wun {
 enum { LOADER_DIRECT = 0, LOADER_DEINT = 1 };
 
 // Epilogue flag bits
-enum { F_LRELU = 1, F_ACCUM = 2, F_VEC4 = 4 };
+enum { F_LRELU = 1, F_ACCUM = 2, F_VEC4 = 4, F_PHASE2 = 8 };
 
 // One implicit-GEMM 1-D convolution launch.  The input is a virtual channel-concat of
 // up to two NCW sources, zero outside [0, Tin) (this is how crop+concat, 'same' zero
@@ -45,6 +45,8 @@ struct ConvArgs {
     int flags;
     int B;
     int loader;
+    int Tlim;        // F_PHASE2: true output length (outputs t = 2q+p < Tlim)
+    int kw_full;     // F_PHASE2: taps of the forward conv (FLOP accounting)
     int cps;         // split-K: channel chunks per split (set by the launcher)
     float* part;     // split-K partial buffer (set by the launcher) or null
 };
@@ -64,6 +66,7 @@ struct WgradArgs {
     const float* dz; long long dzbs; int dzpitch; int N; int Tq;
     float* out; long long split_stride;
     int nsplit; int units_per_split; int nQT; int B;
+    int ablate;      // debugging switches (only read when built with -DWUN_ABLATION)
 };
 
 struct UpsampleArgs {
@@ -97,10 +100,12 @@ struct HeadArgs {
     float gscale;                                          // 2 / (S*B*Tout*C)
 };
 
-struct WtDesc {      // dst[j][n][c] = src[k_last - j*k_step][c][n]
+struct WtDesc {      // mode 0: dst[j][n][c] = src[k_last - j*k_step][c][n]
+                     // mode 1: dst[j][n][p][c] = src[k_last - 2j + p][c][n] (0 if tap >= k_step (= KW))
     long long src_off;   // into params
     long long dst_off;   // into workspace
     int J, C, N, k_last, k_step;
+    int mode;
 };
 
 // ---- launchers (wun_kernels.hip) ---------------------------------------------------
@@ -108,6 +113,7 @@ size_t conv_lds_bytes(const ConvArgs& a, int variant);
 int  conv_pick_variant(const ConvArgs& a);
 hipError_t launch_conv(const ConvArgs& a, float* part, long long part_cap, hipStream_t s);
 double conv_flops(const ConvArgs& a);        // useful FLOPs (2*MACs) of the launch
+long long conv_natural_wgs_phase2(const ConvArgs& a);
 
 int  wgrad_pick_nsplit(const WgradArgs& a);
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s);

@@ -128,8 +128,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
     constexpr int XIT = XIT_D > XIT_I ? XIT_D : XIT_I;
     constexpr int WIT = (WUN_JMAX * CK * NT4 + 255) / 256;
 
+    // two LDS buffers {input window, weight slab}: chunk c+1 is written while chunk c is read
+    const int XB = CK * XP, LB = CK * XP + J * CK * WP;      // floats per X tile / per buffer
     float* Xs = lds;
-    float* Ws = lds + CK * XP;
+    float* Ws = lds + XB;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -145,6 +147,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
     const int wn0 = (wave / WT) * NW * 16;
     const int Ctot = a.C0 + a.C1;
     const bool deint = (a.loader == LOADER_DEINT);
+    const bool phase2 = (a.flags & F_PHASE2) != 0;      // only launched on WN == 1, even NW variants
+    const int n0h = nt * (NT / 2);
     const int UW = TT + J - 1;
     const int CKC = deint ? CH : CK;                 // input channels per chunk
     const int nchunks = (Ctot + CKC - 1) / CKC;
@@ -198,8 +202,20 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
         int k, cch;
         if (!deint) { k = j; cch = r; }
         else { k = 2 * j + r / CH; cch = r % CH; }
-        const bool ok = f < nwvec && k < a.KW && n0 + c4 * 4 < a.N;
-        wofs[i] = ok ? (k * Ctot + cch) * a.N + n0 + c4 * 4 : 0;
+        bool ok;
+        int wo;
+        if (!phase2) {
+            ok = f < nwvec && k < a.KW && n0 + c4 * 4 < a.N;
+            wo = (k * Ctot + cch) * a.N + n0 + c4 * 4;
+        } else {
+            // fused output phases: LDS columns [0, NT/2) hold phase-0 weights of channels
+            // n0h.., columns [NT/2, NT) the phase-1 weights of the SAME channels; global rows
+            // are [2][N] (make_wt mode 1)
+            const int x = c4 * 4, ph = x / (NT / 2), cl = x % (NT / 2);
+            ok = f < nwvec && k < a.KW && n0h + cl < a.N;
+            wo = (k * Ctot + cch) * (2 * a.N) + ph * a.N + n0h + cl;
+        }
+        wofs[i] = ok ? wo : 0;
         wr[i] = cch;
         wmask_s |= (ok ? 1u : 0u) << i;
     }
@@ -221,7 +237,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
             xmask = cok ? xmask_s : 0u;
         }
         const bool tail = c0 + CKC > Ctot;                // uniform; only the last chunk of odd configs
-        const float* wc = a.W + (long long)c0 * a.N;      // uniform base of this chunk's weight rows
+        const float* wc = a.W + (long long)c0 * (phase2 ? 2 * a.N : a.N);   // uniform base of this chunk's weight rows
         wmask = wmask_s;
 #pragma unroll
         for (int i = 0; i < WIT; ++i) {
@@ -244,16 +260,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
         }
     };
     // ---- registers -> LDS (zero fill applied here) ----
-    auto store_chunk = [&]() {
+    auto store_chunk = [&](int bufoff) {
         if (!deint) {
             const int lr = tid % TPR;
-            float* xd = Xs + xrow * XP + lr;
+            float* xd = Xs + bufoff + xrow * XP + lr;
 #pragma unroll
             for (int i = 0; i < XIT_D; ++i)
                 if (lr + i * TPR < UW) xd[i * TPR] = ((xmask >> i) & 1u) ? xreg[i] : 0.f;
         } else {
             const int le = tid % TPC;
-            float* xd = Xs + ((le & 1) * CH + xrow) * XP + (le >> 1);
+            float* xd = Xs + bufoff + ((le & 1) * CH + xrow) * XP + (le >> 1);
 #pragma unroll
             for (int i = 0; i < XIT_I; ++i)
                 if (le + i * TPC < 2 * UW) xd[i * (TPC / 2)] = ((xmask >> i) & 1u) ? xreg[i] : 0.f;
@@ -264,7 +280,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
                 const int f = tid + i * 256;
                 const int row = f / NT4, c4 = f % NT4;
                 if (f < nwvec)
-                    *reinterpret_cast<f32x4*>(&Ws[row * WP + c4 * 4]) =
+                    *reinterpret_cast<f32x4*>(&Ws[bufoff + row * WP + c4 * 4]) =
                         ((wmask >> i) & 1u) ? wreg[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
@@ -272,52 +288,116 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
 
 #ifdef WUN_ABLATION
     const bool ab_noload = a.flags & 256, ab_nostore = a.flags & 512, ab_nomfma = a.flags & 1024,
-               ab_noepi = a.flags & 2048, ab_nobar = a.flags & 4096;
+               ab_noepi = a.flags & 2048, ab_nobar = a.flags & 4096, ab_nolds = a.flags & 8192;
 #else
-    constexpr bool ab_noload = false, ab_nostore = false, ab_nomfma = false, ab_noepi = false, ab_nobar = false;
+    constexpr bool ab_noload = false, ab_nostore = false, ab_nomfma = false, ab_noepi = false, ab_nobar = false, ab_nolds = false;
 #endif
-    if (ch_lo < ch_hi && !ab_noload) load_chunk(ch_lo);
-    for (int chunk = ch_lo; chunk < ch_hi; ++chunk) {
-        if (!ab_nobar) __syncthreads();                 // every wave is done reading the previous chunk
-        if (!ab_nostore) store_chunk();
-        if (!ab_nobar) __syncthreads();
-        if (chunk + 1 < ch_hi && !ab_noload) load_chunk(chunk + 1);   // in flight during the MFMAs below
-        if (!ab_nomfma) {
-            // flat k-steps s = j*KS + ks (4 LDS rows each); operands of step s+1 are read from
-            // LDS while the MFMAs of step s issue (double-buffered registers)
-            constexpr int KS = CK / 4;
-            int nsteps = J * KS;
-            if (deint && CK == 8 && (a.KW & 1)) nsteps -= 1;       // the odd phase has no tap KW
-            const float* xb = Xs + lg * XP + wt0 + li;
-            const float* wbp = Ws + lg * WP + wn0 + li;
-            float a0[MT], b0[NW], a1[MT], b1[NW];
-            auto ldop = [&](int st, float (&av)[MT], float (&bv)[NW]) {
-                const int j = st / KS, ks = st % KS;
-                const float* xa = xb + j + ks * 4 * XP;
-                const float* wb = wbp + (j * CK + ks * 4) * WP;
+    // MFMA loop over the taps [j_begin, j_end) of the chunk in LDS buffer `bufoff`.  A k-step is
+    // 4 LDS rows (4 input channels) of one tap: KS = CK/4 k-steps per tap.  Operands of the
+    // next k-step are read from LDS right after the first MFMA of the current one
+    // (double-buffered registers, pointer-increment addressing), so LDS latency is covered by
+    // the remaining MFMAs.
+    constexpr int KS = CK / 4;
+    const bool skip_last_odd = deint && CK == 8 && (a.KW & 1);     // the odd phase has no tap KW
+    auto run_taps = [&](int bufoff, int j_begin, int j_end) {
+        if (j_end <= j_begin) return;
+        const float* xa = Xs + bufoff + lg * XP + wt0 + li + j_begin;          // tap j, rows 0..3
+        const float* wb = Ws + bufoff + (j_begin * CK + lg) * WP + wn0 + li;
+        const int wstep = CK * WP;
+        float a0[MT], b0[NW], a1[MT], b1[NW];
+        auto ldop = [&](const float* x, const float* w, float (&av)[MT], float (&bv)[NW]) {
+            if (ab_nolds) {
 #pragma unroll
-                for (int m = 0; m < MT; ++m) av[m] = xa[m * 16];
+                for (int m = 0; m < MT; ++m) asm volatile("v_mov_b32 %0, %1" : "=v"(av[m]) : "v"(lane));
 #pragma unroll
-                for (int n = 0; n < NW; ++n) bv[n] = wb[n * 16];
-            };
-            auto mm = [&](const float (&av)[MT], const float (&bv)[NW]) {
+                for (int n = 0; n < NW; ++n) asm volatile("v_mov_b32 %0, %1" : "=v"(bv[n]) : "v"(lane));
+                return;
+            }
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MT; ++m) av[m] = x[m * 16];
 #pragma unroll
-                    for (int n = 0; n < NW; ++n) acc[m][n] = mfma16(av[m], bv[n], acc[m][n]);
-            };
-            if (nsteps > 0) {
-                ldop(0, a0, b0);
-                int st = 0;
-                for (; st + 1 < nsteps; st += 2) {
-                    ldop(st + 1, a1, b1);
-                    mm(a0, b0);
-                    if (st + 2 < nsteps) ldop(st + 2, a0, b0);
-                    mm(a1, b1);
-                }
-                if (nsteps & 1) mm(a0, b0);
+            for (int n = 0; n < NW; ++n) bv[n] = w[n * 16];
+        };
+        auto mm_first = [&](const float (&av)[MT], const float (&bv)[NW]) {
+            acc[0][0] = mfma16(av[0], bv[0], acc[0][0]);
+        };
+        auto mm_rest = [&](const float (&av)[MT], const float (&bv)[NW]) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NW; ++n)
+                    if (m + n > 0) acc[m][n] = mfma16(av[m], bv[n], acc[m][n]);
+        };
+        // pin the per-k-step interleave: 1 MFMA, the LDS reads of the next operands, the rest
+        auto pin = [&]() {
+#ifdef WUN_NOPIN
+            return;
+#endif
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, MT + NW, 0);        // DS reads (<= MT+NW instrs)
+            __builtin_amdgcn_sched_group_barrier(0x008, MT * NW - 1, 0);    // MFMA
+        };
+        ldop(xa, wb, a0, b0);
+        if constexpr (KS == 2) {
+            // the stride-2 loader has no odd-phase rows for its last tap when KW is odd: that
+            // half k-step is peeled off so the loop body stays branch-free
+            const int j_full = (skip_last_odd && j_end == J) ? j_end - 1 : j_end;
+            for (int j = j_begin; j < j_full; ++j) {
+                const bool more = j + 1 < j_end;
+                mm_first(a0, b0);
+                ldop(xa + 4 * XP, wb + 4 * WP, a1, b1);                 // rows 4..7 of tap j
+                mm_rest(a0, b0);
+                pin();
+                xa += more ? 1 : 0;                                     // next tap (clamped at the end)
+                wb += more ? wstep : 0;
+                mm_first(a1, b1);
+                ldop(xa, wb, a0, b0);
+                mm_rest(a1, b1);
+                pin();
+            }
+            if (j_full < j_end) {
+                mm_first(a0, b0);
+                mm_rest(a0, b0);
+            }
+        } else {
+            // one k-step per tap: two taps per iteration, odd tail peeled
+            const int npair = (j_end - j_begin) / 2;
+            int j = j_begin;
+            for (int it = 0; it < npair; ++it, j += 2) {
+                const bool more2 = j + 2 < j_end;
+                mm_first(a0, b0);
+                ldop(xa + 1, wb + wstep, a1, b1);
+                mm_rest(a0, b0);
+                pin();
+                xa += more2 ? 2 : 1;
+                wb += more2 ? 2 * wstep : wstep;
+                mm_first(a1, b1);
+                ldop(xa, wb, a0, b0);
+                mm_rest(a1, b1);
+                pin();
+            }
+            if (j < j_end) {
+                mm_first(a0, b0);
+                mm_rest(a0, b0);
             }
         }
+    };
+
+    // Pipeline: global loads of chunk c+1 are issued before the MFMAs of chunk c; their LDS
+    // writes (to the other buffer) sit in the middle of chunk c's MFMA loop, so they issue in
+    // the shadow of the matrix pipe; one barrier per chunk.
+    if (ch_lo < ch_hi && !ab_noload) load_chunk(ch_lo);
+    if (ch_lo < ch_hi && !ab_nostore) store_chunk(0);
+    __syncthreads();
+    const int half = J / 2;
+    for (int chunk = ch_lo; chunk < ch_hi; ++chunk) {
+        const int cur = ((chunk - ch_lo) & 1) * LB;
+        const bool has_next = chunk + 1 < ch_hi;
+        if (has_next && !ab_noload) load_chunk(chunk + 1);
+        if (!ab_nomfma) run_taps(cur, 0, half);
+        if (has_next && !ab_nostore) store_chunk(LB - cur);
+        if (!ab_nomfma) run_taps(cur, half, J);
+        if (!ab_nobar) __syncthreads();
     }
 
     // ---- split-K: raw partial tile, epilogue runs in conv_splitk_epilogue_kernel ----
@@ -332,6 +412,62 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
             for (int m = 0; m < MT; ++m) {
                 const int q = q0 + wt0 + m * 16 + lg * 4;
                 if (q < TP) *reinterpret_cast<f32x4*>(&prow[q]) = acc[m][n];
+            }
+        }
+        return;
+    }
+
+    // ---- epilogue of the fused two-phase transposed stride-2 conv: tiles [0, NW/2) hold output
+    // phase 0 (t = 2q), tiles [NW/2, NW) phase 1 (t = 2q+1) of the same channels, so a lane
+    // owns 8 consecutive output samples ----
+    if (phase2) {
+        if constexpr (WN == 1 && (NW % 2) == 0) {
+            const bool vec2 = (a.flags & F_VEC4) != 0;
+            const bool accum2 = (a.flags & F_ACCUM) != 0;
+#pragma unroll
+            for (int n = 0; n < NW / 2; ++n) {
+                const int ncol = n0h + n * 16 + li;
+                if (ncol >= a.N) continue;
+                const long long rowbase = (long long)b * a.obs0 + (long long)ncol * a.opitch0 + a.ooff0;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const int q = q0 + wt0 + m * 16 + lg * 4;
+                    const int t0 = 2 * q;
+                    float v[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { v[2 * r] = acc[m][n][r]; v[2 * r + 1] = acc[m][NW / 2 + n][r]; }
+                    if (vec2 && t0 + 7 < a.Tlim) {
+                        const long long idx = rowbase + t0;
+                        if (a.msk0 != nullptr) {
+                            const f32x4 m0 = *reinterpret_cast<const f32x4*>(&a.msk0[idx]);
+                            const f32x4 m1 = *reinterpret_cast<const f32x4*>(&a.msk0[idx + 4]);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                v[r] *= (m0[r] > 0.f) ? 1.f : 0.2f;
+                                v[4 + r] *= (m1[r] > 0.f) ? 1.f : 0.2f;
+                            }
+                        }
+                        if (accum2) {
+                            const f32x4 o0 = *reinterpret_cast<const f32x4*>(&a.dst0[idx]);
+                            const f32x4 o1 = *reinterpret_cast<const f32x4*>(&a.dst0[idx + 4]);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { v[r] += o0[r]; v[4 + r] += o1[r]; }
+                        }
+                        *reinterpret_cast<f32x4*>(&a.dst0[idx]) = (f32x4){v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(&a.dst0[idx + 4]) = (f32x4){v[4], v[5], v[6], v[7]};
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            if (t0 + r < a.Tlim) {
+                                const long long idx = rowbase + t0 + r;
+                                float x = v[r];
+                                if (a.msk0 != nullptr) x *= (a.msk0[idx] > 0.f) ? 1.f : 0.2f;
+                                if (accum2) x += a.dst0[idx];
+                                a.dst0[idx] = x;
+                            }
+                        }
+                    }
+                }
             }
         }
         return;
@@ -442,6 +578,7 @@ static const ConvVariant kConvVariants[] = {
     {1, 2, 2, 2, 8}, {1, 3, 2, 2, 8},                                     // 10..11:  32 x 64/96
     {1, 2, 1, 4, 8},                                                      // 12    :  16 x 128
     {4, 2, 4, 1, 4}, {1, 2, 4, 1, 4},                                     // 13..14: 1-/2-channel audio input
+    {2, 6, 4, 1, 8}, {4, 6, 4, 1, 8},                                     // 15..16: 128/256 x 96 (fused two-phase dgrad)
 };
 
 static inline int conv_J(const ConvArgs& a) { return a.loader == LOADER_DEINT ? (a.KW + 1) / 2 : a.KW; }
@@ -470,6 +607,29 @@ int conv_pick_variant(const ConvArgs& a) {
     return base + (nw - 2);
 }
 
+// fused two-phase transposed conv: per workgroup NT/2 channels x 2 phases; needs even NW, WN == 1
+int conv_pick_variant_phase2(const ConvArgs& a) {
+    const int pad256 = ((a.Tout + 255) / 256) * 256, pad128 = ((a.Tout + 127) / 128) * 128;
+    const bool t128 = pad128 < pad256;
+    int best = 2, bestpad = 1 << 30;                 // channels per workgroup = NW*8
+    const int cands[3] = {6, 4, 2};
+    for (int i = 0; i < 3; ++i) {
+        const int half = cands[i] * 8;
+        const int padded = ((a.N + half - 1) / half) * half;
+        if (padded < bestpad) { bestpad = padded; best = cands[i]; }
+    }
+    if (best == 6) return 15;                        // 128 x 96 keeps 3 waves/SIMD
+    if (best == 4) return t128 ? 6 : 2;
+    return t128 ? 4 : 0;
+}
+
+long long conv_natural_wgs_phase2(const ConvArgs& a) {
+    const int v = conv_pick_variant_phase2(a);
+    const int TT = kConvVariants[v].WT * kConvVariants[v].MT * 16;
+    const int half = kConvVariants[v].NW * 8;
+    return (long long)((a.Tout + TT - 1) / TT) * ((a.N + half - 1) / half) * a.B;
+}
+
 static void conv_geom(const ConvArgs& a, int variant, int& TT, int& NT, int& J, int& XP, int& WP) {
     const ConvVariant& v = kConvVariants[variant];
     TT = v.WT * v.MT * 16;
@@ -483,10 +643,12 @@ size_t conv_lds_bytes(const ConvArgs& a, int variant) {
     int TT, NT, J, XP, WP;
     conv_geom(a, variant, TT, NT, J, XP, WP);
     const int CK = kConvVariants[variant].CK;
-    return sizeof(float) * ((size_t)CK * XP + (size_t)J * CK * WP);
+    return 2 * sizeof(float) * ((size_t)CK * XP + (size_t)J * CK * WP);     // double buffered
 }
 
 double conv_flops(const ConvArgs& a) {
+    if (a.flags & F_PHASE2)   // useful work of the transposed conv: every forward tap once per forward output
+        return 2.0 * a.kw_full * (double)(a.C0 + a.C1) * a.N * (double)a.Tin * a.B;
     return 2.0 * a.KW * (double)(a.C0 + a.C1) * a.N * (double)a.Tout * a.B;
 }
 
@@ -514,7 +676,9 @@ template <int MT, int NW, int WT, int WN, int CK, bool VECW>
 static hipError_t conv_launch_t(ConvArgs a, int variant, float* part, long long part_cap, hipStream_t s) {
     int TT, NT, J, XP, WP;
     conv_geom(a, variant, TT, NT, J, XP, WP);
-    const int nTT = (a.Tout + TT - 1) / TT, nNT = (a.N + NT - 1) / NT;
+    const bool phase2 = (a.flags & F_PHASE2) != 0;
+    const int nTT = (a.Tout + TT - 1) / TT;
+    const int nNT = phase2 ? (a.N + NT / 2 - 1) / (NT / 2) : (a.N + NT - 1) / NT;
     const size_t lds = conv_lds_bytes(a, variant);
     auto kern = conv_mfma_kernel<MT, NW, WT, WN, CK, VECW>;
     static size_t lds_allowed = 64 * 1024;
@@ -523,8 +687,20 @@ static hipError_t conv_launch_t(ConvArgs a, int variant, float* part, long long 
         if (e != hipSuccess) return e;
         lds_allowed = lds;
     }
+#ifdef WUN_ABLATION
+    size_t lds_launch = lds;
+    if (const char* e = getenv("WUN_LDS_PAD")) {
+        lds_launch += (size_t)atoi(e) * 1024;
+        if (lds_launch > lds_allowed) {
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_launch);
+            lds_allowed = lds_launch;
+        }
+    }
+#else
+    const size_t lds_launch = lds;
+#endif
     int ksplit, cps;
-    conv_splitk(a, variant, part != nullptr ? part_cap : 0, ksplit, cps);
+    conv_splitk(a, variant, (part != nullptr && !phase2) ? part_cap : 0, ksplit, cps);
     a.cps = cps;
     a.part = ksplit > 1 ? part : nullptr;
     const long long grid = (long long)nTT * nNT * a.B * ksplit;
@@ -533,7 +709,7 @@ static hipError_t conv_launch_t(ConvArgs a, int variant, float* part, long long 
     snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %s>", MT, NW, WT, WN, CK, VECW ? "true" : "false");
     {
         ProfScope ps(nm, conv_flops(a), s);
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a, nTT, nNT, J, XP, WP);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_launch, s, a, nTT, nNT, J, XP, WP);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || ksplit == 1) return e;
@@ -557,12 +733,13 @@ hipError_t launch_conv(const ConvArgs& a_in, float* part, long long part_cap, hi
     if (a.msk0 != nullptr) vec = vec && aligned16(a.msk0);
     if (a.msk1 != nullptr) vec = vec && aligned16(a.msk1);
     if (a.dec != nullptr) vec = vec && (a.decpitch & 1) == 0 && (a.decbs & 1) == 0;
+    if ((a.flags & F_PHASE2) && !(a.ostride == 1 && a.dst1 == nullptr && vecw)) return hipErrorInvalidValue;
     if (vec) a.flags |= F_VEC4;
 #ifdef WUN_ABLATION
     if (const char* e = getenv("WUN_ABLATE")) a.flags |= atoi(e) << 8;
     if (const char* e = getenv("WUN_NOVEC")) if (atoi(e)) a.flags &= ~F_VEC4;
 #endif
-    int v = conv_pick_variant(a);
+    int v = (a.flags & F_PHASE2) ? conv_pick_variant_phase2(a) : conv_pick_variant(a);
 #ifdef WUN_ABLATION
     if (const char* e = getenv("WUN_VARIANT")) v = atoi(e);
 #endif
@@ -588,6 +765,7 @@ hipError_t launch_conv(const ConvArgs& a_in, float* part, long long part_cap, hi
         WUN_CV(10, 1, 2, 2, 2, 8) WUN_CV(11, 1, 3, 2, 2, 8)
         WUN_CV(12, 1, 2, 1, 4, 8)
         WUN_CV(13, 4, 2, 4, 1, 4) WUN_CV(14, 1, 2, 4, 1, 4)
+        WUN_CV(15, 2, 6, 4, 1, 8) WUN_CV(16, 4, 6, 4, 1, 8)
         default: return hipErrorInvalidValue;
     }
 #undef WUN_CV
@@ -668,41 +846,58 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a, int nMG
     const float inv_xw4 = 1.0f / (float)XW4, inv_tk4 = 1.0f / (float)TK4;
 
     // Buffers are in the plan's canonical layout: row pitch % 4 == 0, 16-byte aligned rows,
-    // off + Tin <= pitch.  Every vector is loaded from an in-row clamped position; the zero
-    // fill (virtual time outside [0, Tin), rows beyond the group) is applied when the
-    // registers are written to LDS, so the loads stay in flight during the previous unit.
+    // off + Tin <= pitch.  Every vector is loaded from an in-row clamped position; zero fill
+    // (virtual time outside [0, Tin), q beyond the batch) is applied at the LDS write and only
+    // for units that touch a boundary, so interior units stage with almost no VALU work.
+    // Unit-invariant per-vector state is computed once:
+    //   xro[i] = element offset of the vector's source row (relative to the batch base)
+    //   xpk[i] = (LDS float offset << 10) | c4, bit 31 = this thread stages vector i, bit 30 = src1
+    int xro[WUN_WG_XIT], xpk[WUN_WG_XIT];
+    int zro[ZIT], zpk[ZIT];
+#pragma unroll
+    for (int i = 0; i < WUN_WG_XIT; ++i) {
+        const int f = tid + i * 256;
+        const int row = (int)(((float)f + 0.5f) * inv_xw4);
+        const int c4 = f - row * XW4;
+        const bool rok = row < nCh;
+        const int c = cLo + (rok ? row : 0);
+        const bool s0 = c < a.C0;
+        xro[i] = s0 ? c * a.pitch0 : (c - a.C0) * a.pitch1;
+        const int ldsoff = deint ? (row * 2) * XP + 2 * c4 : row * XP + 4 * c4;
+        xpk[i] = rok ? (int)(0x80000000u | (s0 ? 0u : 0x40000000u) | ((unsigned)ldsoff << 10) | (unsigned)c4) : c4;
+    }
+#pragma unroll
+    for (int i = 0; i < ZIT; ++i) {
+        const int f = tid + i * 256;
+        const int row = (int)(((float)f + 0.5f) * inv_tk4);
+        const int c4 = f - row * TK4;
+        const int nn = ng * NG + row;
+        zro[i] = ((row < NG && nn < a.N) ? nn : 0) * a.dzpitch;
+        zpk[i] = row < NG ? (int)(0x80000000u | ((unsigned)(row * ZP + 4 * c4) << 10) | (unsigned)c4) : c4;
+    }
+
     auto load_unit = [&](int u) {
         const int b = u / a.nQT, qt = u - b * a.nQT;
         const int q0 = qt * TK;
         const int tb = (deint ? 2 * q0 : q0) - a.shift;
         const float* base0 = a.src0 + (long long)b * a.bs0;
         const float* base1 = (a.C1 > 0) ? a.src1 + (long long)b * a.bs1 : base0;
+        const int e00 = (tb + a.off0) & ~3, e01 = (tb + a.off1) & ~3;   // uniform element shift per source
 #pragma unroll
         for (int i = 0; i < WUN_WG_XIT; ++i) {
-            const int f = tid + i * 256;
-            const int row = (int)(((float)f + 0.5f) * inv_xw4);
-            const int c4 = f - row * XW4;
-            const int c = cLo + (row < nCh ? row : 0);
-            const bool s0 = c < a.C0;
-            const int off = s0 ? a.off0 : a.off1;
-            const int pitch = s0 ? a.pitch0 : a.pitch1;
-            const int e0 = ((tb + off) & ~3) + 4 * c4;           // element index in the row (multiple of 4)
-            int e0c = e0 < 0 ? 0 : e0;
-            if (e0c > pitch - 4) e0c = pitch - 4;
-            const int rel = (s0 ? c * a.pitch0 : (c - a.C0) * a.pitch1) + e0c;
-            xreg[i] = *reinterpret_cast<const f32x4*>((s0 ? base0 : base1) + rel);
+            const bool s1 = (xpk[i] & 0x40000000) != 0;
+            int e = (s1 ? e01 : e00) + ((xpk[i] & 1023) << 2);         // element index inside the row
+            const int emax = (s1 ? a.pitch1 : a.pitch0) - 4;
+            e = e < 0 ? 0 : (e > emax ? emax : e);
+            xreg[i] = *reinterpret_cast<const f32x4*>((s1 ? base1 : base0) + xro[i] + e);
         }
-        const float* zb = a.dz + (long long)b * a.dzbs + q0;
+        const float* zb = a.dz + (long long)b * a.dzbs;
+        const int qmax = a.dzpitch - 4;
 #pragma unroll
         for (int i = 0; i < ZIT; ++i) {
-            const int f = tid + i * 256;
-            const int row = (int)(((float)f + 0.5f) * inv_tk4);
-            const int c4 = f - row * TK4;
-            int nn = ng * NG + row;
-            if (!(row < NG && nn < a.N)) nn = 0;
-            int qq = 4 * c4;
-            if (q0 + qq > a.dzpitch - 4) qq = a.dzpitch - 4 - q0;
-            zreg[i] = *reinterpret_cast<const f32x4*>(zb + (long long)nn * a.dzpitch + qq);
+            int q = q0 + ((zpk[i] & 1023) << 2);
+            q = q > qmax ? qmax : q;
+            zreg[i] = *reinterpret_cast<const f32x4*>(zb + zro[i] + q);
         }
     };
     auto store_unit = [&](int u) {
@@ -710,61 +905,67 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a, int nMG
         const int q0 = qt * TK;
         const int tb = (deint ? 2 * q0 : q0) - a.shift;
         int nq = a.Tq - q0; if (nq > TK) nq = TK;
+        // interior unit: every staged element has 0 <= t < Tin for both sources -> no masking
+        const int span = 4 * XW4;
+        const int t00 = ((tb + a.off0) & ~3) - a.off0, t01 = ((tb + a.off1) & ~3) - a.off1;
+        const bool xedge = t00 < 0 || t00 + span > a.Tin || (a.C1 > 0 && (t01 < 0 || t01 + span > a.Tin));
 #pragma unroll
         for (int i = 0; i < WUN_WG_XIT; ++i) {
-            const int f = tid + i * 256;
-            const int row = (int)(((float)f + 0.5f) * inv_xw4);
-            const int c4 = f - row * XW4;
-            if (row < nCh) {
-                const int c = cLo + row;
-                const int off = (c < a.C0) ? a.off0 : a.off1;
-                const int t0 = ((tb + off) & ~3) + 4 * c4 - off;     // virtual time of element 0
+            if (xpk[i] < 0) {
                 f32x4 v = xreg[i];
+                if (xedge) {
+                    const int t0 = ((xpk[i] & 0x40000000) ? t01 : t00) + ((xpk[i] & 1023) << 2);
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (t0 + k < 0 || t0 + k >= a.Tin) v[k] = 0.f;
+                    for (int k = 0; k < 4; ++k)
+                        if (t0 + k < 0 || t0 + k >= a.Tin) v[k] = 0.f;
+                }
+                float* dstp = Xs + ((xpk[i] >> 10) & 0xFFFFF);
                 if (!deint) {
-                    *reinterpret_cast<f32x4*>(&Xs[row * XP + 4 * c4]) = v;
+                    *reinterpret_cast<f32x4*>(dstp) = v;
                 } else {
-                    float* p0 = &Xs[(row * 2) * XP + 2 * c4];
-                    float* p1 = &Xs[(row * 2 + 1) * XP + 2 * c4];
-                    *reinterpret_cast<float2*>(p0) = make_float2(v[0], v[2]);
-                    *reinterpret_cast<float2*>(p1) = make_float2(v[1], v[3]);
+                    *reinterpret_cast<float2*>(dstp) = make_float2(v[0], v[2]);
+                    *reinterpret_cast<float2*>(dstp + XP) = make_float2(v[1], v[3]);
                 }
             }
         }
+        const bool zedge = nq < TK;
 #pragma unroll
         for (int i = 0; i < ZIT; ++i) {
-            const int f = tid + i * 256;
-            const int row = (int)(((float)f + 0.5f) * inv_tk4);
-            const int c4 = f - row * TK4;
-            if (row < NG) {
-                const bool rok = ng * NG + row < a.N;
+            if (zpk[i] < 0) {
                 f32x4 v = zreg[i];
+                if (zedge) {
+                    const int c4x = (zpk[i] & 1023) << 2;
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (!rok || 4 * c4 + k >= nq) v[k] = 0.f;
-                float* p = &Zs[row * ZP + 4 * c4];
+                    for (int k = 0; k < 4; ++k)
+                        if (c4x + k >= nq) v[k] = 0.f;
+                }
+                float* p = Zs + ((zpk[i] >> 10) & 0xFFFFF);
                 *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
                 *reinterpret_cast<float2*>(p + 2) = make_float2(v[2], v[3]);
             }
         }
+        (void)b;
     };
 
     const int nunits = a.B * a.nQT;
     const int u0 = split * a.units_per_split;
     int u1 = u0 + a.units_per_split;
     if (u1 > nunits) u1 = nunits;
-    if (u0 < u1) load_unit(u0);
+#ifdef WUN_ABLATION
+    const bool wb_noload = a.ablate & 1, wb_nostore = a.ablate & 2, wb_nomfma = a.ablate & 4, wb_noepi = a.ablate & 8;
+#else
+    constexpr bool wb_noload = false, wb_nostore = false, wb_nomfma = false, wb_noepi = false;
+#endif
+    if (u0 < u1 && !wb_noload) load_unit(u0);
     for (int u = u0; u < u1; ++u) {
         const int qt = u % a.nQT;
         int nq = a.Tq - qt * TK; if (nq > TK) nq = TK;
         const int nsteps = (nq + 3) >> 2;
         __syncthreads();
-        store_unit(u);
+        if (!wb_nostore) store_unit(u);
         __syncthreads();
-        if (u + 1 < u1) load_unit(u + 1);
-        {
+        if (u + 1 < u1 && !wb_noload) load_unit(u + 1);
+        if (!wb_nomfma) {
             float a0[MTW], b0[NW], a1[MTW], b1[NW];
             auto ldop = [&](int st, float (&av)[MTW], float (&bv)[NW]) {
 #pragma unroll
@@ -781,19 +982,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a, int nMG
                     }
                 }
             };
+            const int last = nsteps - 1;
             ldop(0, a0, b0);
-            int st = 0;
-            for (; st + 1 < nsteps; st += 2) {
-                ldop(st + 1, a1, b1);
+            for (int st = 0; st < nsteps; st += 2) {
+                ldop(st + 1 < last ? st + 1 : last, a1, b1);
                 mm(a0, b0);
-                if (st + 2 < nsteps) ldop(st + 2, a0, b0);
-                mm(a1, b1);
+                ldop(st + 2 < last ? st + 2 : last, a0, b0);
+                if (st + 1 < nsteps) mm(a1, b1);
             }
-            if (nsteps & 1) mm(a0, b0);
         }
     }
 
     float* outp = a.out + (long long)split * a.split_stride;
+    if (wb_noepi && acc[0][0][0] != 12345.678f) return;
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
         if (mt >= nact) continue;
@@ -900,6 +1101,9 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
     if ((a.dzpitch & 3) || (a.dzbs & 3) || (reinterpret_cast<uintptr_t>(a.dz) & 15) || a.dzpitch < 4) return hipErrorInvalidValue;
     const WgradGeom g = wgrad_geom(a);
     if ((long long)g.nChMax * g.XW4 > (long long)WUN_WG_XIT * 256) return hipErrorInvalidValue;
+#ifdef WUN_ABLATION
+    if (const char* e = getenv("WUN_ABLATE")) const_cast<WgradArgs&>(a).ablate = atoi(e);
+#endif
 #define WUN_WG(M, N) if (g.MTW == M && g.NW == N) return wgrad_launch_t<M, N>(a, g, s);
     WUN_WG(1, 1) WUN_WG(1, 2) WUN_WG(1, 3)
     WUN_WG(2, 1) WUN_WG(2, 2) WUN_WG(2, 3)
@@ -1227,20 +1431,37 @@ hipError_t launch_btc_to_ncw(const float* src, float* dst, int B, int T, int C, 
     return hipGetLastError();
 }
 
+__device__ __forceinline__ void make_wt_body(const float* __restrict__ src, float* __restrict__ dst,
+                                             const WtDesc& d) {
+    if (d.mode == 0) {
+        const long long total = (long long)d.J * d.N * d.C;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+             i += (long long)gridDim.x * blockDim.x) {
+            const int c = (int)(i % d.C);
+            const long long jn = i / d.C;
+            const int n = (int)(jn % d.N), j = (int)(jn / d.N);
+            const int k = d.k_last - j * d.k_step;
+            dst[i] = src[((long long)k * d.C + c) * d.N + n];
+        }
+    } else {
+        // fused output phases: dst[j][n][p][c] = src[k_last - 2j + p][c][n]  (0 where that tap does not exist)
+        const long long total = (long long)d.J * d.N * 2 * d.C;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+             i += (long long)gridDim.x * blockDim.x) {
+            const int c = (int)(i % d.C);
+            long long r = i / d.C;
+            const int ph = (int)(r % 2); r /= 2;
+            const int n = (int)(r % d.N), j = (int)(r / d.N);
+            const int k = d.k_last - 2 * j + ph;
+            dst[i] = (k >= 0 && k < d.k_step) ? src[((long long)k * d.C + c) * d.N + n] : 0.f;
+        }
+    }
+}
+
 __global__ void make_wt_kernel(const float* __restrict__ params, float* __restrict__ ws,
                                const WtDesc* __restrict__ descs) {
     const WtDesc d = descs[blockIdx.y];
-    const long long total = (long long)d.J * d.N * d.C;
-    const float* src = params + d.src_off;
-    float* dst = ws + d.dst_off;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % d.C);
-        const long long jn = i / d.C;
-        const int n = (int)(jn % d.N), j = (int)(jn / d.N);
-        const int k = d.k_last - j * d.k_step;
-        dst[i] = src[((long long)k * d.C + c) * d.N + n];
-    }
+    make_wt_body(params + d.src_off, ws + d.dst_off, d);
 }
 
 hipError_t launch_make_wt(const float* params, float* ws, const WtDesc* dev_descs, int ndesc,
@@ -1254,19 +1475,11 @@ hipError_t launch_make_wt(const float* params, float* ws, const WtDesc* dev_desc
 }
 
 __global__ void make_wt_one_kernel(const float* __restrict__ src, float* __restrict__ dst, WtDesc d) {
-    const long long total = (long long)d.J * d.N * d.C;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % d.C);
-        const long long jn = i / d.C;
-        const int n = (int)(jn % d.N), j = (int)(jn / d.N);
-        const int k = d.k_last - j * d.k_step;
-        dst[i] = src[((long long)k * d.C + c) * d.N + n];
-    }
+    make_wt_body(src, dst, d);
 }
 
 hipError_t launch_make_wt_one(const float* src, float* dst, WtDesc d, hipStream_t s) {
-    const long long total = (long long)d.J * d.N * d.C;
+    const long long total = (long long)d.J * d.N * d.C * (d.mode == 1 ? 2 : 1);
     long long blocks = (total + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) return hipSuccess;

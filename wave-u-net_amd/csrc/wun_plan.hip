@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -81,7 +82,7 @@ extern "C" int wun_get_padding(const wun_config* cfg, int64_t desired, int64_t* 
 // ---------------------------------------------------------------------------------------
 struct Buf { long long off = -1; int C = 0; int T = 0; int pitch = 0; long long bs = 0; };
 struct ConvLayer { long long woff = 0, boff = 0; int KW = 0, Cin = 0, Cout = 0;
-                   long long wt_full = -1, wt_ph[2] = {-1, -1}; int Jp[2] = {0, 0}; };
+                   long long wt_full = -1, wt_ph[2] = {-1, -1}, wt_ph2 = -1; int Jp[2] = {0, 0}; int J0 = 0; };
 struct DownShape { int cin, cout, t_in, t_conv, t_dec, tc, cs; };
 struct UpShape { int c_skip, c_cur, cout, t_cur, t_up, t_conv, crop_start; };
 
@@ -109,6 +110,12 @@ struct wun_plan {
     WtDesc* dev_wt = nullptr;
     int wt_max = 0;
     double fwd_flops = 0, bwd_flops = 0, fwd_dense = 0;
+    // second HIP stream: independent launches (weight gradients vs the input-gradient chain;
+    // skip-window convs vs the decimating convs) run concurrently so that one kernel's tail and
+    // epilogue overlap another kernel's MFMA phase
+    mutable hipStream_t side = nullptr;
+    mutable std::vector<hipEvent_t> events;
+    mutable size_t ev_next = 0;
 };
 
 static long long bump(long long& cur, long long n) {
@@ -262,10 +269,20 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
     // ---- transposed / tap-flipped weights for the input-gradient convs ----
     auto add_wt = [&](const ConvLayer& cl, int J, int k_last, int k_step) -> long long {
         WtDesc d;
-        d.src_off = cl.woff; d.J = J; d.C = cl.Cin; d.N = cl.Cout; d.k_last = k_last; d.k_step = k_step;
+        d.src_off = cl.woff; d.J = J; d.C = cl.Cin; d.N = cl.Cout; d.k_last = k_last; d.k_step = k_step; d.mode = 0;
         d.dst_off = bump(w, (long long)J * cl.Cin * cl.Cout);
         p->wt.push_back(d);
         const long long n = (long long)J * cl.Cin * cl.Cout;
+        if (n > p->wt_max) p->wt_max = (int)n;
+        return d.dst_off;
+    };
+    // both output phases of the transposed stride-2 conv side by side: [J0][Cout][2][Cin]
+    auto add_wt2 = [&](const ConvLayer& cl, int J0) -> long long {
+        WtDesc d;
+        d.src_off = cl.woff; d.J = J0; d.C = cl.Cin; d.N = cl.Cout; d.k_last = 2 * (J0 - 1); d.k_step = cl.KW; d.mode = 1;
+        const long long n = (long long)J0 * cl.Cin * cl.Cout * 2;
+        d.dst_off = bump(w, n);
+        p->wt.push_back(d);
         if (n > p->wt_max) p->wt_max = (int)n;
         return d.dst_off;
     };
@@ -278,6 +295,8 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
                 cl.Jp[ph] = Jp;
                 cl.wt_ph[ph] = add_wt(cl, Jp, 2 * (Jp - 1) + ph, 2);
             }
+            cl.J0 = (cl.KW + 1) / 2;
+            cl.wt_ph2 = add_wt2(cl, cl.J0);
         }
     }
     p->bott.wt_full = add_wt(p->bott, Kd, Kd - 1, 1);
@@ -341,6 +360,8 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
 extern "C" void wun_plan_destroy(wun_plan* p) {
     if (!p) return;
     if (p->dev_wt) (void)hipFree(p->dev_wt);
+    for (auto e : p->events) (void)hipEventDestroy(e);
+    if (p->side) (void)hipStreamDestroy(p->side);
     delete p;
 }
 
@@ -422,6 +443,27 @@ static HeadArgs head_args(const wun_plan* p, const float* params, float* ws, flo
     return h;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// two-stream helpers
+// ---------------------------------------------------------------------------------------
+static int side_init(const wun_plan* p) {
+    if (p->side != nullptr) return WUN_OK;
+    if (getenv("WUN_SINGLE_STREAM") != nullptr) return WUN_OK;      // debugging: everything on one stream
+    HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+    p->events.resize(96);
+    for (auto& e : p->events) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return WUN_OK;
+}
+// `to` waits for everything issued so far on `from`
+static int stream_dep(const wun_plan* p, hipStream_t from, hipStream_t to) {
+    if (from == to) return WUN_OK;
+    hipEvent_t e = p->events[p->ev_next++ % p->events.size()];
+    HIP_TRY(hipEventRecord(e, from));
+    HIP_TRY(hipStreamWaitEvent(to, e, 0));
+    return WUN_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // forward: get_output (UnetAudioSeparator.py:85-144)
 // ---------------------------------------------------------------------------------------
@@ -432,6 +474,10 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
     const int L = p->L, Kd = p->cfg.filter_size, Ku = p->cfg.merge_filter_size;
     const bool same = p->same;
     const int padD = same ? (Kd - 1) / 2 : 0, padU = same ? (Ku - 1) / 2 : 0;
+    int rc0;
+    if ((rc0 = side_init(p))) return rc0;
+    hipStream_t s2 = p->side ? p->side : s;          // side stream (skip-window convs)
+    bool side_used = false;
 
     HIP_TRY(launch_btc_to_ncw(mix_btc, ws + p->mix_ncw.off, p->B, p->Tin, p->C, p->mix_ncw.pitch, s));
 
@@ -446,8 +492,10 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
             a.KW = Kd; a.N = a.N0 = d.cout; a.Tout = d.t_conv; a.flags = F_LRELU;
             set_dst0(a, ws, p->skip[i], 0, nullptr);
             a.dec = ws + p->dec[i].off; a.decbs = p->dec[i].bs; a.decpitch = p->dec[i].pitch;
-            HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats, s));
+            HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
         } else {
+            // x (written on `s`) is ready for both convs of this level: the side stream may start
+            if ((rc0 = stream_dep(p, s, s2))) return rc0;
             // stride-2 conv straight into the decimated stream (odd outputs are never observed)
             ConvArgs a = conv_base(p);
             set_src0(a, ws, *x, 0, d.cin);
@@ -455,14 +503,16 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
             a.Tin = d.t_in; a.shift = 0; a.W = params + cl.woff; a.bias = params + cl.boff;
             a.KW = Kd; a.N = a.N0 = d.cout; a.Tout = d.t_dec; a.flags = F_LRELU;
             set_dst0(a, ws, p->dec[i], 0, nullptr);
-            HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats, s));
-            // full-rate conv only over the window the skip connection crops (Utils.py:104-123)
+            HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
+            // full-rate conv only over the window the skip connection crops (Utils.py:104-123);
+            // independent of the decimating conv -> side stream, own half of the split-K scratch
             ConvArgs b = conv_base(p);
             set_src0(b, ws, *x, d.cs, d.cin);
             b.Tin = d.tc + Kd - 1; b.shift = 0; b.W = params + cl.woff; b.bias = params + cl.boff;
             b.KW = Kd; b.N = b.N0 = d.cout; b.Tout = d.tc; b.flags = F_LRELU;
             set_dst0(b, ws, p->skip[i], 0, nullptr);
-            HIP_TRY(launch_conv(b, ws + p->conv_part_off, p->conv_part_floats, s));
+            HIP_TRY(launch_conv(b, ws + p->conv_part_off + p->conv_part_floats / 2, p->conv_part_floats / 2, s2));
+            side_used = side_used || (s2 != s);
         }
         x = &p->dec[i];
     }
@@ -472,8 +522,9 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
         a.Tin = p->t_b_in; a.shift = padD; a.W = params + p->bott.woff; a.bias = params + p->bott.boff;
         a.KW = Kd; a.N = a.N0 = p->c_b; a.Tout = p->t_b; a.flags = F_LRELU;
         set_dst0(a, ws, p->bott_out, 0, nullptr);
-        HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats, s));
+        HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
     }
+    if (side_used && (rc0 = stream_dep(p, s2, s))) return rc0;     // the up path reads the skip windows
     const Buf* cur = &p->bott_out;
     for (int j = 0; j < L; ++j) {                                   // :107-125
         const UpShape& u = p->ush[j];
@@ -490,7 +541,7 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
         a.Tin = u.t_up; a.shift = padU; a.W = params + p->up[j].woff; a.bias = params + p->up[j].boff;
         a.KW = Ku; a.N = a.N0 = u.cout; a.Tout = u.t_conv; a.flags = F_LRELU;
         set_dst0(a, ws, p->upo[j], 0, nullptr);
-        HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats, s));
+        HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
         cur = &p->upo[j];
     }
     HeadArgs h = head_args(p, params, ws, outputs, training);
@@ -504,7 +555,12 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
 // loss + backward
 // ---------------------------------------------------------------------------------------
 static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const ConvLayer& cl, float* ws,
-                     float* grads, hipStream_t s) {
+                     float* grads, hipStream_t main, hipStream_t s) {
+    // everything this weight gradient reads (dz, activations) has been issued on `main`
+    {
+        int rcd = stream_dep(p, main, s);
+        if (rcd) return rcd;
+    }
     const long long blk = (long long)cl.KW * cl.Cin * cl.Cout + cl.Cout;
     int total = 0;
     for (int i = 0; i < nparts; ++i) {
@@ -541,6 +597,8 @@ extern "C" int wun_loss_backward(const wun_plan* p, const float* params, const f
     const int padD = same ? (Kd - 1) / 2 : 0, padU = same ? (Ku - 1) / 2 : 0;
     const int F = p->cfg.num_initial_filters, C = p->C;
     int rc;
+    if ((rc = side_init(p))) return rc;
+    hipStream_t s2 = p->side ? p->side : s;          // side stream: weight gradients + their reductions
 
     HIP_TRY(launch_make_wt(params, ws, p->dev_wt, (int)p->wt.size(), p->wt_max, s));
 
@@ -558,7 +616,7 @@ extern "C" int wun_loss_backward(const wun_plan* p, const float* params, const f
         wset_src1(w, ws, p->upo[L - 1], 0, F);
         w.Tin = p->t_feat; w.shift = h.padl; w.KW = Ko;
         wset_dz(w, h.dpre + (long long)sh * h.dps, h.dpbs, h.dppitch, C, p->Tout);
-        if ((rc = run_wgrad(p, &w, 1, p->head[sh], ws, grads, s))) return rc;
+        if ((rc = run_wgrad(p, &w, 1, p->head[sh], ws, grads, s, s2))) return rc;
     }
 
     // ---- up path, last level first ----
@@ -571,7 +629,7 @@ extern "C" int wun_loss_backward(const wun_plan* p, const float* params, const f
             wset_src1(w, ws, p->ups[j], 0, u.c_cur);
             w.Tin = u.t_up; w.shift = padU; w.KW = Ku;
             wset_dz(w, ws + p->dz_upo[j].off, p->dz_upo[j].bs, p->dz_upo[j].pitch, u.cout, u.t_conv);
-            if ((rc = run_wgrad(p, &w, 1, p->up[j], ws, grads, s))) return rc;
+            if ((rc = run_wgrad(p, &w, 1, p->up[j], ws, grads, s, s2))) return rc;
         }
         {
             ConvArgs a = conv_base(p);
@@ -580,7 +638,7 @@ extern "C" int wun_loss_backward(const wun_plan* p, const float* params, const f
             a.N = u.c_skip + u.c_cur; a.N0 = u.c_skip; a.Tout = u.t_up;
             set_dst0(a, ws, p->dz_skip[i], 0, &p->skip[i]);
             set_dst1(a, ws, p->d_ups[j], 0, nullptr);
-            HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats, s));
+            HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
         }
         {
             const Buf& prev = (j == 0) ? p->bott_out : p->upo[j - 1];
@@ -603,7 +661,7 @@ extern "C" int wun_loss_backward(const wun_plan* p, const float* params, const f
         wset_src0(w, ws, p->dec[L - 1], 0, p->bott.Cin);
         w.Tin = p->t_b_in; w.shift = padD; w.KW = Kd;
         wset_dz(w, ws + p->dz_bott.off, p->dz_bott.bs, p->dz_bott.pitch, p->c_b, p->t_b);
-        if ((rc = run_wgrad(p, &w, 1, p->bott, ws, grads, s))) return rc;
+        if ((rc = run_wgrad(p, &w, 1, p->bott, ws, grads, s, s2))) return rc;
         ConvArgs a = conv_base(p);
         set_src0(a, ws, p->dz_bott, 0, p->c_b);
         a.Tin = p->t_b; a.shift = Kd - 1 - padD; a.W = ws + p->bott.wt_full; a.KW = Kd;
@@ -614,7 +672,7 @@ extern "C" int wun_loss_backward(const wun_plan* p, const float* params, const f
         } else {
             set_dst0(a, ws, p->dz_dec[L - 1], 0, &p->dec[L - 1]);
         }
-        HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats, s));
+        HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
     }
 
     // ---- down path ----
@@ -627,7 +685,7 @@ extern "C" int wun_loss_backward(const wun_plan* p, const float* params, const f
             wset_src0(w, ws, x, 0, d.cin);
             w.Tin = d.t_in; w.shift = padD; w.KW = Kd;
             wset_dz(w, ws + p->dz_skip[i].off, p->dz_skip[i].bs, p->dz_skip[i].pitch, d.cout, d.t_conv);
-            if ((rc = run_wgrad(p, &w, 1, cl, ws, grads, s))) return rc;
+            if ((rc = run_wgrad(p, &w, 1, cl, ws, grads, s, s2))) return rc;
             if (i > 0) {
                 ConvArgs a = conv_base(p);
                 set_src0(a, ws, p->dz_skip[i], 0, d.cout);
@@ -635,7 +693,7 @@ extern "C" int wun_loss_backward(const wun_plan* p, const float* params, const f
                 a.N = a.N0 = d.cin; a.Tout = d.t_in;
                 set_dst0(a, ws, p->dz_skip[i - 1], 0, &p->skip[i - 1]);
                 a.ostride = 2; a.flags = F_ACCUM;
-                HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats, s));
+                HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
             }
         } else {
             WgradArgs w[2];
@@ -647,16 +705,28 @@ extern "C" int wun_loss_backward(const wun_plan* p, const float* params, const f
             wset_src0(w[1], ws, x, d.cs, d.cin);
             w[1].Tin = d.tc + Kd - 1; w[1].shift = 0; w[1].KW = Kd;
             wset_dz(w[1], ws + p->dz_skip[i].off, p->dz_skip[i].bs, p->dz_skip[i].pitch, d.cout, d.tc);
-            if ((rc = run_wgrad(p, w, 2, cl, ws, grads, s))) return rc;
+            if ((rc = run_wgrad(p, w, 2, cl, ws, grads, s, s2))) return rc;
             if (i > 0) {
-                for (int ph = 0; ph < 2; ++ph) {       // transposed stride-2 conv, one output phase at a time
-                    ConvArgs a = conv_base(p);
-                    set_src0(a, ws, p->dz_dec[i], 0, d.cout);
-                    a.Tin = d.t_dec; a.KW = cl.Jp[ph]; a.shift = cl.Jp[ph] - 1; a.W = ws + cl.wt_ph[ph];
-                    a.N = a.N0 = d.cin; a.Tout = (d.t_in - ph + 1) / 2;
-                    set_dst0(a, ws, p->dz_dec[i - 1], ph, &p->dec[i - 1]);
-                    a.ostride = 2;
-                    HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats, s));
+                // transposed stride-2 conv: both output phases fused in one launch (a lane owns 8
+                // consecutive outputs) when the launch fills the chip, else one phase at a time
+                // (those launches can use split-K)
+                ConvArgs f = conv_base(p);
+                set_src0(f, ws, p->dz_dec[i], 0, d.cout);
+                f.Tin = d.t_dec; f.KW = cl.J0; f.kw_full = Kd; f.shift = cl.J0 - 1; f.W = ws + cl.wt_ph2;
+                f.N = f.N0 = d.cin; f.Tout = (d.t_in + 1) / 2; f.Tlim = d.t_in; f.flags = F_PHASE2;
+                set_dst0(f, ws, p->dz_dec[i - 1], 0, &p->dec[i - 1]);
+                if ((d.cin & 3) == 0 && conv_natural_wgs_phase2(f) >= 256) {
+                    HIP_TRY(launch_conv(f, ws + p->conv_part_off, p->conv_part_floats / 2, s));
+                } else {
+                    for (int ph = 0; ph < 2; ++ph) {
+                        ConvArgs a = conv_base(p);
+                        set_src0(a, ws, p->dz_dec[i], 0, d.cout);
+                        a.Tin = d.t_dec; a.KW = cl.Jp[ph]; a.shift = cl.Jp[ph] - 1; a.W = ws + cl.wt_ph[ph];
+                        a.N = a.N0 = d.cin; a.Tout = (d.t_in - ph + 1) / 2;
+                        set_dst0(a, ws, p->dz_dec[i - 1], ph, &p->dec[i - 1]);
+                        a.ostride = 2;
+                        HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
+                    }
                 }
                 ConvArgs a = conv_base(p);
                 set_src0(a, ws, p->dz_skip[i], 0, d.cout);
@@ -664,10 +734,11 @@ extern "C" int wun_loss_backward(const wun_plan* p, const float* params, const f
                 a.N = a.N0 = d.cin; a.Tout = d.tc + Kd - 1;
                 set_dst0(a, ws, p->dz_dec[i - 1], d.cs, &p->dec[i - 1]);
                 a.flags = F_ACCUM;
-                HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats, s));
+                HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
             }
         }
     }
+    if ((rc = stream_dep(p, s2, s))) return rc;      // all gradients are complete w.r.t. `stream`
     return WUN_OK;
 }
 
@@ -775,7 +846,7 @@ extern "C" int wun_op_conv1d_dgrad(const float* dz, const float* w, float* dx, f
     if (stride != 1 && stride != 2) return fail(WUN_ERR_UNSUPPORTED, "stride must be 1 or 2");
     hipStream_t s = (hipStream_t)stream;
     if (stride == 1) {
-        WtDesc d; d.src_off = 0; d.dst_off = 0; d.J = k; d.C = cin; d.N = cout; d.k_last = k - 1; d.k_step = 1;
+        WtDesc d; d.src_off = 0; d.dst_off = 0; d.J = k; d.C = cin; d.N = cout; d.k_last = k - 1; d.k_step = 1; d.mode = 0;
         HIP_TRY(launch_make_wt_one(w, wt_scratch, d, s));
         ConvArgs a;
         memset(&a, 0, sizeof(a));
@@ -786,11 +857,26 @@ extern "C" int wun_op_conv1d_dgrad(const float* dz, const float* w, float* dx, f
         HIP_TRY(launch_conv(a, op_scratch(), kOpScratchFloats, s));
     } else {
         if (pad_left != 0) return fail(WUN_ERR_UNSUPPORTED, "stride-2 dgrad supports pad_left == 0 only");
+        const int J0 = (k + 1) / 2;
+        ConvArgs f;
+        memset(&f, 0, sizeof(f));
+        f.B = batch; f.ostride = 1;
+        op_src(f, dz, cout, t_out);
+        f.Tin = t_out; f.KW = J0; f.kw_full = k; f.shift = J0 - 1; f.W = wt_scratch; f.N = f.N0 = cin;
+        f.Tout = (t_in + 1) / 2; f.Tlim = t_in; f.flags = F_PHASE2;
+        f.dst0 = dx; f.obs0 = (long long)cin * t_in; f.opitch0 = t_in;
+        if ((cin & 3) == 0 && conv_natural_wgs_phase2(f) >= 64) {
+            WtDesc d; d.src_off = 0; d.dst_off = 0; d.J = J0; d.C = cin; d.N = cout; d.k_last = 2 * (J0 - 1);
+            d.k_step = k; d.mode = 1;
+            HIP_TRY(launch_make_wt_one(w, wt_scratch, d, s));
+            HIP_TRY(launch_conv(f, op_scratch(), kOpScratchFloats, s));
+            return WUN_OK;
+        }
         for (int ph = 0; ph < 2; ++ph) {
             const int Jp = (k - ph + 1) / 2;
             float* wt = wt_scratch + (long long)ph * k * cin * cout;
             WtDesc d; d.src_off = 0; d.dst_off = 0; d.J = Jp; d.C = cin; d.N = cout;
-            d.k_last = 2 * (Jp - 1) + ph; d.k_step = 2;
+            d.k_last = 2 * (Jp - 1) + ph; d.k_step = 2; d.mode = 0;
             if (Jp > 0) HIP_TRY(launch_make_wt_one(w, wt, d, s));
             ConvArgs a;
             memset(&a, 0, sizeof(a));
