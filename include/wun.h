@@ -140,7 +140,9 @@ int wun_op_mfma_probe(const float* a, const float* b, float* d, void* stream);
 
 /* Per-kernel timing with HIP events recorded on the launch stream around every heavy launch
  * between begin and end; end() synchronises and writes a JSON summary
- * {"kernels":[{"name","launches","ms","flops"}]} (used by bench.py for the roofline line). */
+ * {"kernels":[{"name","launches","ms","flops"}]} (used by bench.py for the roofline line).
+ * While active, the library's internal side stream is not used, so launch durations are not
+ * distorted by concurrent kernels. */
 int wun_profile_begin(void);
 int wun_profile_end(char* json_out, int64_t capacity);
 

@@ -1064,6 +1064,9 @@ int wgrad_pick_nsplit(const WgradArgs& a) {
     const long long units = (long long)a.B * nQT;
     const long long per = (long long)g.nMG * g.nNG;
     long long ns = (1024 + per - 1) / per;
+    // big weight blocks: every split writes+reads the whole block once, so aim lower (512 workgroups)
+    const long long blk = (long long)a.KW * (a.C0 + a.C1) * a.N;
+    if (blk > (1ll << 18)) ns = (512 + per - 1) / per;
     if (ns > units) ns = units;
     if (ns < 1) ns = 1;
     // keep each split at >= 2 units when there is plenty of work, to amortise the epilogue
@@ -1394,16 +1397,21 @@ __global__ __launch_bounds__(256) void head_dfeat_kernel(HeadArgs a, long long h
     }
 }
 
-__global__ void loss_finish_kernel(const float* partial, int n, float scale, float* loss) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        float s = 0.f;
-        for (int i = 0; i < n; ++i) s += partial[i];
-        *loss = s * scale;
+__global__ __launch_bounds__(256) void loss_finish_kernel(const float* partial, int n, float scale, float* loss) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];     // fixed order -> deterministic
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
     }
+    if (threadIdx.x == 0) *loss = red[0] * scale;
 }
 
 hipError_t launch_loss_finish(const float* partial, int n, float scale, float* loss, hipStream_t s) {
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, s, partial, n, scale, loss);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, s, partial, n, scale, loss);
     return hipGetLastError();
 }
 
@@ -1458,17 +1466,49 @@ __device__ __forceinline__ void make_wt_body(const float* __restrict__ src, floa
     }
 }
 
-__global__ void make_wt_kernel(const float* __restrict__ params, float* __restrict__ ws,
-                               const WtDesc* __restrict__ descs) {
+// tiled [C][N] -> [N][C] transpose per tap through LDS: coalesced on both sides.
+// grid.x = tiles, blockIdx.y = descriptor; block = 256 threads = 32 x 8
+__global__ __launch_bounds__(256) void make_wt_kernel(const float* __restrict__ params, float* __restrict__ ws,
+                                                      const WtDesc* __restrict__ descs) {
+    __shared__ float tile[32][33];
     const WtDesc d = descs[blockIdx.y];
-    make_wt_body(params + d.src_off, ws + d.dst_off, d);
+    const float* src = params + d.src_off;
+    float* dst = ws + d.dst_off;
+    const int tc = (d.C + 31) / 32, tn = (d.N + 31) / 32;
+    const int nph = d.mode == 1 ? 2 : 1;
+    const int ntiles = d.J * nph * tc * tn;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        int r = t;
+        const int in_ = r % tn; r /= tn;
+        const int ic = r % tc; r /= tc;
+        const int ph = r % nph; const int j = r / nph;
+        const int k = d.mode == 1 ? d.k_last - 2 * j + ph : d.k_last - j * d.k_step;
+        const bool kok = d.mode == 1 ? (k >= 0 && k < d.k_step) : true;
+        __syncthreads();
+#pragma unroll
+        for (int yy = 0; yy < 4; ++yy) {
+            const int c = ic * 32 + ty + yy * 8, n = in_ * 32 + tx;
+            tile[ty + yy * 8][tx] = (kok && c < d.C && n < d.N) ? src[((long long)k * d.C + c) * d.N + n] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int yy = 0; yy < 4; ++yy) {
+            const int n = in_ * 32 + ty + yy * 8, c = ic * 32 + tx;
+            if (n < d.N && c < d.C) {
+                const long long o = d.mode == 1 ? (((long long)j * d.N + n) * 2 + ph) * d.C + c
+                                                : ((long long)j * d.N + n) * d.C + c;
+                dst[o] = tile[tx][ty + yy * 8];
+            }
+        }
+    }
 }
 
 hipError_t launch_make_wt(const float* params, float* ws, const WtDesc* dev_descs, int ndesc,
                           int max_elems, hipStream_t s) {
     if (ndesc <= 0) return hipSuccess;
-    int bx = (max_elems + 255) / 256;
-    if (bx > 256) bx = 256;
+    int bx = (max_elems + 1023) / 1024;
+    if (bx > 128) bx = 128;
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(make_wt_kernel, dim3(bx, ndesc), dim3(256), 0, s, params, ws, dev_descs);
     return hipGetLastError();

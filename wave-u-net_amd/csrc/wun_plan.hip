@@ -17,6 +17,7 @@ hipError_t launch_make_wt_one(const float* src, float* dst, WtDesc d, hipStream_
 }
 
 static thread_local std::string g_err;
+static bool g_profiling = false;   // while wun_profile_* is active everything runs on the caller's stream
 
 static int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -476,7 +477,7 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
     const int padD = same ? (Kd - 1) / 2 : 0, padU = same ? (Ku - 1) / 2 : 0;
     int rc0;
     if ((rc0 = side_init(p))) return rc0;
-    hipStream_t s2 = p->side ? p->side : s;          // side stream (skip-window convs)
+    hipStream_t s2 = (p->side && !g_profiling) ? p->side : s;   // side stream (skip-window convs)
     bool side_used = false;
 
     HIP_TRY(launch_btc_to_ncw(mix_btc, ws + p->mix_ncw.off, p->B, p->Tin, p->C, p->mix_ncw.pitch, s));
@@ -598,7 +599,7 @@ extern "C" int wun_loss_backward(const wun_plan* p, const float* params, const f
     const int F = p->cfg.num_initial_filters, C = p->C;
     int rc;
     if ((rc = side_init(p))) return rc;
-    hipStream_t s2 = p->side ? p->side : s;          // side stream: weight gradients + their reductions
+    hipStream_t s2 = (p->side && !g_profiling) ? p->side : s;   // side stream: weight gradients + their reductions
 
     HIP_TRY(launch_make_wt(params, ws, p->dev_wt, (int)p->wt.size(), p->wt_max, s));
 
@@ -896,10 +897,11 @@ extern "C" int wun_op_mfma_probe(const float* a, const float* b, float* d, void*
     return WUN_OK;
 }
 
-extern "C" int wun_profile_begin(void) { prof_begin(); return WUN_OK; }
+extern "C" int wun_profile_begin(void) { g_profiling = true; prof_begin(); return WUN_OK; }
 
 extern "C" int wun_profile_end(char* json_out, int64_t capacity) {
     const std::string js = prof_end();
+    g_profiling = false;
     if (!json_out || capacity < (int64_t)js.size() + 1) return fail(WUN_ERR_INVALID, "profile buffer too small");
     memcpy(json_out, js.c_str(), js.size() + 1);
     return WUN_OK;
