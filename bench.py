@@ -55,6 +55,20 @@ def usable_cores():
     return max(1, n)
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/round1_pmc_traffic.json: FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE,
+    separate passes); PMC counters cannot be collected from inside this process."""
+    path = os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")
+    try:
+        table = json.load(open(path))["kernels"]
+    except Exception:
+        return None
+    key = kernel_name.replace(", true>", ">").replace(", false>", ">")
+    ent = table.get(key)
+    return ent["hbm_bytes_per_launch"] if ent else None
+
+
 def cpu_baseline(cfg_name, cfg_over, budget_s=20.0):
     """The oracle (torch-CPU fp32 restatement of the reference graph; TensorFlow 1.8 cannot be
     installed) timed on this box's host cores on a bounded sample of the same workload."""
@@ -185,7 +199,7 @@ def main():
             achieved = top["flops"] / top["launches"] / (avg_ms * 1e-3) / 1e12
             result["roofline"] = {
                 "bound": "mfma", "kernel": top["name"], "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(top["name"]),
                 "avg_launch_ms": avg_ms, "launches_per_step": top["launches"] / nprof,
                 "flops_per_launch": top["flops"] / top["launches"],
                 "kernel_ms_per_step": {k["name"]: k["ms"] / nprof for k in kernels},

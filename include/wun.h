@@ -106,6 +106,17 @@ int wun_loss_backward(const wun_plan* plan, const float* params, const float* mi
                       float* workspace, const float* outputs, const float* targets,
                       float* grads, float* loss, void* stream);
 
+/* Same as wun_loss_backward, plus data-parallel overlap hooks: bucket k covers arena floats
+ * [bucket_starts[k], end) where `end` is the previous bucket's start (buckets are given from the
+ * END of the arena towards 0, i.e. in backward completion order).  bucket_events[k] (hipEvent_t,
+ * created by the caller) is recorded -- on an internal stream -- as soon as every gradient at an
+ * offset >= bucket_starts[k] is final, so the caller can start that bucket's all-reduce on a
+ * communication stream (hipStreamWaitEvent) while the rest of the backward pass still runs. */
+int wun_loss_backward_ex(const wun_plan* plan, const float* params, const float* mix_btc,
+                         float* workspace, const float* outputs, const float* targets,
+                         float* grads, float* loss, void* stream,
+                         const int64_t* bucket_starts, void* const* bucket_events, int32_t nbuckets);
+
 /* tf.train.AdamOptimizer update (Training.py:77), TF rule:
  *   lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v; theta -= lr_t*m/(sqrt(v)+eps); g := grad_scale*grad
  * step is 1-based.  grad_scale = 1/world_size after a sum all-reduce. */

@@ -351,3 +351,45 @@ def test_inference_mode_clip(lib):
         assert ev[n].abs().max().item() <= 1.0
     tr = sep.get_output(torch.from_numpy(mix).cuda(), True)
     assert max(tr[n].abs().max().item() for n in ocfg["source_names"]) > 1.0
+
+
+def test_overlapped_allreduce_plumbing_world1(lib):
+    """The bucket-event hooks of wun_loss_backward_ex + the overlapped reducer, exercised with a
+    1-rank RCCL group (the all-reduce of one rank is the identity, so gradients must be
+    bit-identical to the plain path); multi-rank semantics are covered on CPU/gloo."""
+    import socket
+    import torch.distributed as dist
+    from wave_u_net_amd.parallel import OverlappedGradAllReducer
+    case = GOLDEN_CASES["full_small"]
+    ocfg = _ocfg(case)
+    params = golden_params(ocfg, case["seed"])
+    sep, cfg = _make_sep(case, params)
+    B = 4
+    i, o = shapes.get_padding(ocfg, [B, case["frames"], 0])
+    mix, targets = wt.synthetic_batch(ocfg, B, i[1], o[1], seed=3)
+    tg = torch.stack([torch.from_numpy(targets[n]) for n in ocfg["source_names"]]).cuda()
+    plan = sep._plan(B, i[1]); sep._active = plan
+    sep.load_variables(params)
+    dmix = torch.from_numpy(mix).cuda()
+    sep.get_output(dmix, True)
+    l0 = sep.loss_and_gradients(tg).clone()
+    g0 = sep.grads.clone()
+    created = False
+    if not dist.is_initialized():
+        sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+        created = True
+    try:
+        red = OverlappedGradAllReducer(plan.tensors, plan.info.arena_floats, bucket_mib=0.02, device=sep._dev())
+        assert len(red.buckets) >= 3
+        for _ in range(3):
+            sep.get_output(dmix, True)
+            l1 = sep.loss_and_gradients(tg, *red.begin())
+            red.launch(sep.grads, force=True)
+            red.finish()
+            torch.cuda.synchronize()
+            assert torch.equal(l1, l0) and torch.equal(sep.grads, g0)
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -586,10 +586,34 @@ static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const Conv
     return WUN_OK;
 }
 
+struct BucketSignal {
+    const int64_t* starts; void* const* events; int n; int next;   // buckets in descending start order
+    // every gradient at arena offset >= floor is final with respect to stream `st`
+    int ready(long long floor, hipStream_t st) {
+        while (next < n && starts[next] >= floor) {
+            hipError_t e = hipEventRecord((hipEvent_t)events[next], st);
+            if (e != hipSuccess) return fail(WUN_ERR_HIP, std::string("hipEventRecord(bucket): ") + hipGetErrorString(e));
+            ++next;
+        }
+        return WUN_OK;
+    }
+};
+
 extern "C" int wun_loss_backward(const wun_plan* p, const float* params, const float* mix_btc, float* ws,
                                  const float* outputs, const float* targets, float* grads, float* loss,
                                  void* stream) {
+    return wun_loss_backward_ex(p, params, mix_btc, ws, outputs, targets, grads, loss, stream, nullptr, nullptr, 0);
+}
+
+extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, const float* mix_btc, float* ws,
+                                    const float* outputs, const float* targets, float* grads, float* loss,
+                                    void* stream, const int64_t* bucket_starts, void* const* bucket_events,
+                                    int32_t nbuckets) {
     (void)mix_btc;
+    if (nbuckets < 0 || (nbuckets > 0 && (!bucket_starts || !bucket_events))) return fail(WUN_ERR_INVALID, "bad bucket arguments");
+    for (int k = 1; k < nbuckets; ++k)
+        if (bucket_starts[k] >= bucket_starts[k - 1]) return fail(WUN_ERR_INVALID, "bucket_starts must be strictly descending");
+    BucketSignal sig{bucket_starts, bucket_events, nbuckets, 0};
     if (!p || !params || !ws || !outputs || !targets || !grads || !loss) return fail(WUN_ERR_INVALID, "null argument");
     if (!p->wt.empty() && !p->dev_wt) return fail(WUN_ERR_HIP, "plan was created without a usable HIP device");
     hipStream_t s = (hipStream_t)stream;
@@ -619,6 +643,7 @@ extern "C" int wun_loss_backward(const wun_plan* p, const float* params, const f
         wset_dz(w, h.dpre + (long long)sh * h.dps, h.dpbs, h.dppitch, C, p->Tout);
         if ((rc = run_wgrad(p, &w, 1, p->head[sh], ws, grads, s, s2))) return rc;
     }
+    if (p->Sh > 0 && (rc = sig.ready(p->head[0].woff, s2))) return rc;
 
     // ---- up path, last level first ----
     for (int j = L - 1; j >= 0; --j) {
@@ -631,6 +656,9 @@ extern "C" int wun_loss_backward(const wun_plan* p, const float* params, const f
             w.Tin = u.t_up; w.shift = padU; w.KW = Ku;
             wset_dz(w, ws + p->dz_upo[j].off, p->dz_upo[j].bs, p->dz_upo[j].pitch, u.cout, u.t_conv);
             if ((rc = run_wgrad(p, &w, 1, p->up[j], ws, grads, s, s2))) return rc;
+            // (interp_j, written on `s` by the previous level's upsample_bwd, sits above up[j] in
+            // the arena; run_wgrad made s2 wait for everything issued on `s` so far)
+            if ((rc = sig.ready(p->up[j].woff, s2))) return rc;
         }
         {
             ConvArgs a = conv_base(p);
@@ -663,6 +691,7 @@ extern "C" int wun_loss_backward(const wun_plan* p, const float* params, const f
         w.Tin = p->t_b_in; w.shift = padD; w.KW = Kd;
         wset_dz(w, ws + p->dz_bott.off, p->dz_bott.bs, p->dz_bott.pitch, p->c_b, p->t_b);
         if ((rc = run_wgrad(p, &w, 1, p->bott, ws, grads, s, s2))) return rc;
+        if ((rc = sig.ready(p->bott.woff, s2))) return rc;
         ConvArgs a = conv_base(p);
         set_src0(a, ws, p->dz_bott, 0, p->c_b);
         a.Tin = p->t_b; a.shift = Kd - 1 - padD; a.W = ws + p->bott.wt_full; a.KW = Kd;
@@ -687,6 +716,7 @@ extern "C" int wun_loss_backward(const wun_plan* p, const float* params, const f
             w.Tin = d.t_in; w.shift = padD; w.KW = Kd;
             wset_dz(w, ws + p->dz_skip[i].off, p->dz_skip[i].bs, p->dz_skip[i].pitch, d.cout, d.t_conv);
             if ((rc = run_wgrad(p, &w, 1, cl, ws, grads, s, s2))) return rc;
+            if ((rc = sig.ready(cl.woff, s2))) return rc;
             if (i > 0) {
                 ConvArgs a = conv_base(p);
                 set_src0(a, ws, p->dz_skip[i], 0, d.cout);
@@ -707,6 +737,7 @@ extern "C" int wun_loss_backward(const wun_plan* p, const float* params, const f
             w[1].Tin = d.tc + Kd - 1; w[1].shift = 0; w[1].KW = Kd;
             wset_dz(w[1], ws + p->dz_skip[i].off, p->dz_skip[i].bs, p->dz_skip[i].pitch, d.cout, d.tc);
             if ((rc = run_wgrad(p, w, 2, cl, ws, grads, s, s2))) return rc;
+            if ((rc = sig.ready(cl.woff, s2))) return rc;
             if (i > 0) {
                 // transposed stride-2 conv: both output phases fused in one launch (a lane owns 8
                 // consecutive outputs) when the launch fills the chip, else one phase at a time
@@ -740,6 +771,7 @@ extern "C" int wun_loss_backward(const wun_plan* p, const float* params, const f
         }
     }
     if ((rc = stream_dep(p, s2, s))) return rc;      // all gradients are complete w.r.t. `stream`
+    if ((rc = sig.ready(0, s))) return rc;           // any bucket not yet signalled (e.g. single-stream mode)
     return WUN_OK;
 }
 

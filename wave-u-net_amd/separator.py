@@ -199,11 +199,15 @@ class UnetAudioSeparator(object):
         return {name: outs[i] for i, name in enumerate(self.source_names)}
 
     # ------------------------------------------------------------------ training step pieces
-    def loss_and_gradients(self, targets):
+    def loss_and_gradients(self, targets, bucket_starts=None, bucket_events=None):
         """MSE loss averaged over sources (Training.py:50-63) and its gradient w.r.t. every
         separator variable.  targets: dict source_name -> [B, Tout, C] or a stacked
         [S, B, Tout, C] tensor.  Must follow get_output(training=True).  Returns the loss as
-        a 0-dim GPU tensor (no host sync)."""
+        a 0-dim GPU tensor (no host sync).
+
+        bucket_starts / bucket_events (optional, data parallel): arena offsets in descending
+        order and one torch.cuda.Event per bucket; event k is recorded as soon as all gradients
+        at offsets >= bucket_starts[k] are final (see include/wun.h, wun_loss_backward_ex)."""
         if self._active is None or not self._last_training:
             raise RuntimeError("call get_output(..., training=True) first")
         dev = self._dev()
@@ -216,10 +220,13 @@ class UnetAudioSeparator(object):
         if tuple(tg.shape) != tuple(outs.shape):
             raise ValueError("targets shape %s != outputs shape %s" % (tuple(tg.shape), tuple(outs.shape)))
         loss = torch.empty((), dtype=torch.float32, device=dev)
-        _lib.check(self._lib.wun_loss_backward(
+        nb = len(bucket_starts) if bucket_starts else 0
+        starts = (C.c_int64 * max(nb, 1))(*([int(x) for x in bucket_starts] if nb else [0]))
+        events = (C.c_void_p * max(nb, 1))(*([int(e.cuda_event) for e in bucket_events] if nb else [0]))
+        _lib.check(self._lib.wun_loss_backward_ex(
             self._active.handle, self.params.data_ptr(), self._last_mix.data_ptr(),
             self._ws[self._last_key].data_ptr(), outs.data_ptr(), tg.data_ptr(),
-            self.grads.data_ptr(), loss.data_ptr(), self._stream()))
+            self.grads.data_ptr(), loss.data_ptr(), self._stream(), starts, events, nb))
         return loss
 
     def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):

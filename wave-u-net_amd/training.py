@@ -14,7 +14,7 @@ import time
 import numpy as np
 import torch
 
-from .parallel import GradAllReducer, broadcast_parameters, init_distributed
+from .parallel import GradAllReducer, OverlappedGradAllReducer, broadcast_parameters, init_distributed
 from .separator import UnetAudioSeparator
 
 
@@ -58,13 +58,24 @@ class Trainer(object):
         self.sep._active = plan
         self.sep._ensure_variables(plan)
         broadcast_parameters(self.sep.params)
-        self.reducer = GradAllReducer(plan.tensors, plan.info.arena_floats, bucket_mib)
+        self.overlap = self.world > 1 and os.environ.get("WUN_NO_OVERLAP") is None
+        if self.overlap:
+            self.reducer = OverlappedGradAllReducer(plan.tensors, plan.info.arena_floats, bucket_mib,
+                                                    device=self.device)
+        else:
+            self.reducer = GradAllReducer(plan.tensors, plan.info.arena_floats, bucket_mib)
         self.lr = model_config["init_sup_sep_lr"]
 
     def step(self, mix, targets):
         self.sep.get_output(mix, True)
-        loss = self.sep.loss_and_gradients(targets)
-        self.reducer.all_reduce(self.sep.grads)
+        if self.overlap:
+            # bucket events are recorded by the backward pass; the all-reduces wait on them
+            loss = self.sep.loss_and_gradients(targets, *self.reducer.begin())
+            self.reducer.launch(self.sep.grads)
+            self.reducer.finish()
+        else:
+            loss = self.sep.loss_and_gradients(targets)
+            self.reducer.all_reduce(self.sep.grads)
         self.sep.adam_step(self.lr, grad_scale=self.reducer.grad_scale)
         return loss
 
