@@ -80,11 +80,13 @@ class Trainer(object):
         return loss
 
 
-def train(model_config, experiment_id, load_model=None, batch_source=None, log_every=100):
+def train(model_config, experiment_id, load_model=None, batch_source=None, log_every=None):
     """Training.train(model_config, experiment_id, load_model=None) -> save_path
     (Training.py:24-25,121)."""
     if model_config["network"] != "unet":
         raise NotImplementedError(model_config["network"])         # Training.py:28-33
+    if log_every is None:
+        log_every = 100 if model_config["epoch_it"] > 100 else 1
     tr = Trainer(model_config)
     if load_model is not None:
         state = np.load(load_model)
