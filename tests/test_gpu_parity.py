@@ -393,3 +393,69 @@ def test_overlapped_allreduce_plumbing_world1(lib):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+FULL_SIZE_CONFIGS = {
+    # BASELINE.json configs[2..4] architectures at full size (fp32), one or two excerpts
+    "M4_baseline_stereo": dict(output_type="difference", context=True, mono_downmix=False),
+    "M5_full_learned": dict(output_type="difference", context=True, upsampling="learned", mono_downmix=False),
+    "M6_full_multi_instrument": dict(output_type="difference", context=True, mono_downmix=False,
+                                     task="multi_instrument"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FULL_SIZE_CONFIGS))
+def test_full_size_named_configs_step_vs_oracle(lib, name):
+    over = FULL_SIZE_CONFIGS[name]
+    ocfg = shapes.finalize_config(dict(shapes.BASE_MODEL_CONFIG, **over))
+    params = golden_params(ocfg, 91)
+    sep = UnetAudioSeparator(wun.get_config("baseline", **over), device="cuda:0")
+    B = 2
+    i, o = shapes.get_padding(ocfg, [B, 16384, 0])
+    assert (i[1], o[1]) == (147443, 16389)
+    mix, targets = wt.synthetic_batch(ocfg, B, i[1], o[1], seed=92)
+    sep._plan(B, i[1]); sep._active = sep._plans[(B, i[1])]
+    sep.load_variables(params)
+    outs = sep.get_output(torch.from_numpy(mix).cuda(), True)
+    loss = sep.loss_and_gradients({k: torch.from_numpy(v) for k, v in targets.items()})
+    torch.cuda.synchronize()
+    tp = wt.params_to_torch(params, torch.float32, requires_grad=True)
+    tmix = torch.from_numpy(mix)
+    oloss, ograds = wt.train_step(ocfg, tp, tmix, {k: torch.from_numpy(v) for k, v in targets.items()})
+    oouts = wt.get_output(ocfg, tp, tmix, True)
+    for n in ocfg["source_names"]:
+        assert (outs[n].cpu() - oouts[n].detach()).abs().max().item() <= 2e-4, n
+    # difference output: the sources add up to the cropped mix (OutputLayer.py:20-22)
+    total = sum(outs[n] for n in ocfg["source_names"]).cpu()
+    pad = (i[1] - o[1]) // 2
+    assert (total - tmix[:, pad:i[1] - pad, :]).abs().max().item() <= 1e-5
+    assert abs(loss.item() - oloss.item()) <= 2e-5 * abs(oloss.item())
+    _grad_check(sep, tp, [g.double() for g in ograds], tol=5e-3)
+
+
+def test_deep_variant_16_levels_48_filters(lib):
+    """BASELINE.json configs[4] architecture: 16 levels, 48 base channels, stereo, 4 sources,
+    same padding, 589824-sample excerpt (9 * 2^16), 92.45 M parameters -- one excerpt, fp32:
+    forward vs the oracle, loss, and a subset of gradient tensors (the oracle's backward of this
+    model takes tens of seconds on the host)."""
+    over = dict(num_layers=16, num_initial_filters=48, mono_downmix=False, task="multi_instrument",
+                output_type="difference")
+    ocfg = shapes.finalize_config(dict(shapes.BASE_MODEL_CONFIG, **over))
+    assert shapes.num_params(ocfg) == 92452098
+    params = golden_params(ocfg, 93)
+    sep = UnetAudioSeparator(wun.get_config("baseline", **over), device="cuda:0")
+    T = 589824
+    mix, targets = wt.synthetic_batch(ocfg, 1, T, T, seed=94)
+    sep._plan(1, T); sep._active = sep._plans[(1, T)]
+    sep.load_variables(params)
+    outs = sep.get_output(torch.from_numpy(mix).cuda(), True)
+    loss = sep.loss_and_gradients({k: torch.from_numpy(v) for k, v in targets.items()})
+    torch.cuda.synchronize()
+    assert torch.isfinite(sep.grads).all()
+    tp = wt.params_to_torch(params, torch.float32, requires_grad=True)
+    oloss, ograds = wt.train_step(ocfg, tp, torch.from_numpy(mix), {k: torch.from_numpy(v) for k, v in targets.items()})
+    oouts = wt.get_output(ocfg, tp, torch.from_numpy(mix), True)
+    for n in ocfg["source_names"]:
+        assert (outs[n].cpu() - oouts[n].detach()).abs().max().item() <= 5e-4, n
+    assert abs(loss.item() - oloss.item()) <= 5e-5 * abs(oloss.item())
+    _grad_check(sep, tp, [g.double() for g in ograds], tol=1e-2)
