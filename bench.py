@@ -133,6 +133,9 @@ def main():
         if world > 1:
             dist.barrier()
 
+    t_tune = time.time()
+    tr.tune(mix, targets)                      # one-off autotuning of the per-launch tilings (untimed)
+    log("autotune: %.2f s" % (time.time() - t_tune))
     for _ in range(args.warmup):
         loss = tr.step(mix, targets)
     torch.cuda.synchronize()
@@ -186,9 +189,13 @@ def main():
             tr.step(mix, targets)
         torch.cuda.synchronize()
         if tr.rank == 0:
-            buf = ctypes.create_string_buffer(1 << 16)
+            buf = ctypes.create_string_buffer(1 << 20)
             _lib.check(lib.wun_profile_end(buf, len(buf)))
-            kernels = json.loads(buf.value.decode())["kernels"]
+            prof = json.loads(buf.value.decode())
+            if prof.get("launches") and os.environ.get("WUN_PROFILE_DETAIL"):
+                with open(os.environ["WUN_PROFILE_DETAIL"], "w") as f:
+                    json.dump(prof["launches"], f)
+            kernels = prof["kernels"]
             kernels.sort(key=lambda k: -k["ms"])
             for k in kernels:
                 log("  %-42s launches/step %5.1f  ms/step %8.3f  TFLOP/s %7.2f" % (

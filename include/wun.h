@@ -117,6 +117,15 @@ int wun_loss_backward_ex(const wun_plan* plan, const float* params, const float*
                          float* grads, float* loss, void* stream,
                          const int64_t* bucket_starts, void* const* bucket_events, int32_t nbuckets);
 
+/* Optional autotuning pass (no reference counterpart): runs one forward + loss/backward on the
+ * given buffers while timing, for every conv / weight-gradient launch of the step, the candidate
+ * tile shapes and split factors, and caches the fastest per launch in the plan.  The contents of
+ * outputs / loss / grads / workspace after this call are NOT meaningful (accumulating launches are
+ * replayed while timing): run the real step afterwards.  Parameters and optimizer state are not
+ * touched.  Synchronises the stream. */
+int wun_plan_tune(const wun_plan* plan, const float* params, const float* mix_btc, float* workspace,
+                  float* outputs, const float* targets, float* grads, float* loss, void* stream);
+
 /* tf.train.AdamOptimizer update (Training.py:77), TF rule:
  *   lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v; theta -= lr_t*m/(sqrt(v)+eps); g := grad_scale*grad
  * step is 1-based.  grad_scale = 1/world_size after a sum all-reduce. */

@@ -459,3 +459,52 @@ def test_deep_variant_16_levels_48_filters(lib):
         assert (outs[n].cpu() - oouts[n].detach()).abs().max().item() <= 5e-4, n
     assert abs(loss.item() - oloss.item()) <= 5e-5 * abs(oloss.item())
     _grad_check(sep, tp, [g.double() for g in ograds], tol=1e-2)
+
+
+@pytest.mark.parametrize("name", ["full_multi_small", "baseline_small"])
+def test_autotuned_plan_keeps_parity(lib, name):
+    """wun_plan_tune only changes tilings / split factors: results stay within the fp32 tolerances
+    and remain bit-deterministic afterwards."""
+    case = GOLDEN_CASES[name]
+    ocfg = _ocfg(case)
+    params = golden_params(ocfg, case["seed"])
+    sep, cfg = _make_sep(case, params)
+    B = 3
+    i, o = shapes.get_padding(ocfg, [B, case["frames"], 0])
+    mix, targets = wt.synthetic_batch(ocfg, B, i[1], o[1], seed=case["seed"] + 7)
+    sep._plan(B, i[1]); sep._active = sep._plans[(B, i[1])]
+    sep.load_variables(params)
+    dmix = torch.from_numpy(mix).cuda()
+    tg = {k: torch.from_numpy(v) for k, v in targets.items()}
+    sep.tune(dmix, tg)
+    outs = sep.get_output(dmix, True)
+    loss = sep.loss_and_gradients(tg).clone()
+    g1 = sep.grads.clone()
+    tp = wt.params_to_torch(params, torch.float64, requires_grad=True)
+    oloss, ograds = wt.train_step(ocfg, tp, torch.tensor(mix, dtype=torch.float64),
+                                  {k: torch.tensor(v, dtype=torch.float64) for k, v in targets.items()})
+    assert abs(loss.item() - oloss.item()) <= 1e-5 * max(abs(oloss.item()), 1e-3)
+    _grad_check(sep, tp, ograds)
+    sep.get_output(dmix, True)
+    l2 = sep.loss_and_gradients(tg)
+    assert torch.equal(l2, loss) and torch.equal(sep.grads, g1)
+
+
+def test_autotuned_full_size_m1_context(lib):
+    ocfg = shapes.finalize_config(dict(shapes.BASE_MODEL_CONFIG, context=True))
+    params = golden_params(ocfg, 77)
+    sep = UnetAudioSeparator(wun.get_config("m1_context"), device="cuda:0")
+    B = 2
+    i, o = shapes.get_padding(ocfg, [B, 16384, 0])
+    mix, targets = wt.synthetic_batch(ocfg, B, i[1], o[1], seed=78)
+    sep._plan(B, i[1]); sep._active = sep._plans[(B, i[1])]
+    sep.load_variables(params)
+    tg = {k: torch.from_numpy(v) for k, v in targets.items()}
+    sep.tune(torch.from_numpy(mix).cuda(), tg)
+    sep.get_output(torch.from_numpy(mix).cuda(), True)
+    loss = sep.loss_and_gradients(tg)
+    torch.cuda.synchronize()
+    tp = wt.params_to_torch(params, torch.float32, requires_grad=True)
+    oloss, ograds = wt.train_step(ocfg, tp, torch.from_numpy(mix), tg)
+    assert abs(loss.item() - oloss.item()) <= 2e-5 * abs(oloss.item())
+    _grad_check(sep, tp, [g.double() for g in ograds], tol=5e-3)

@@ -38,6 +38,7 @@ _SIGS = {
     "wun_forward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _P]),
     "wun_loss_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "wun_loss_backward_ex": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.c_int32]),
+    "wun_plan_tune": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "wun_adam_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float,
                                 C.c_float, C.c_float, _P]),
     "wun_op_conv1d": (C.c_int, [_P, _P, _P, _P] + [C.c_int] * 9 + [_P]),

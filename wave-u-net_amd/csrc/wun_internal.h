@@ -47,6 +47,8 @@ struct ConvArgs {
     int loader;
     int Tlim;        // F_PHASE2: true output length (outputs t = 2q+p < Tlim)
     int kw_full;     // F_PHASE2: taps of the forward conv (FLOP accounting)
+    int force_variant;   // autotuner: tile variant index + 1 (0 = heuristic)
+    int force_ksplit;    // autotuner: split-K factor (0 = heuristic)
     int cps;         // split-K: channel chunks per split (set by the launcher)
     float* part;     // split-K partial buffer (set by the launcher) or null
 };
@@ -67,7 +69,11 @@ struct WgradArgs {
     float* out; long long split_stride;
     int nsplit; int units_per_split; int nQT; int B;
     int ablate;      // debugging switches (only read when built with -DWUN_ABLATION)
+    int force_mtw, force_nw;   // autotuner: geometry overrides (0 = heuristic)
 };
+
+struct ConvChoice { int variant; int ksplit; };
+struct WgradChoice { int mtw, nw, nsplit; };
 
 struct UpsampleArgs {
     const float* x; long long xbs; int xpitch; int n;     // [B][C][n]
@@ -114,6 +120,8 @@ int  conv_pick_variant(const ConvArgs& a);
 hipError_t launch_conv(const ConvArgs& a, float* part, long long part_cap, hipStream_t s);
 double conv_flops(const ConvArgs& a);        // useful FLOPs (2*MACs) of the launch
 long long conv_natural_wgs_phase2(const ConvArgs& a);
+int conv_list_candidates(const ConvArgs& a, long long part_cap, ConvChoice* out, int maxn);
+int wgrad_max_units(const WgradArgs& a);
 
 int  wgrad_pick_nsplit(const WgradArgs& a);
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s);

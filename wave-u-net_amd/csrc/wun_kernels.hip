@@ -42,7 +42,7 @@ __host__ __device__ static inline int fit_pitch(int width, int mod32) {
 // =====================================================================================
 // optional per-launch timing (HIP events on the launch stream), used by bench.py
 // =====================================================================================
-struct ProfSlot { std::string name; double flops; hipEvent_t e0, e1; };
+struct ProfSlot { std::string name; std::string tag; double flops; hipEvent_t e0, e1; };
 static std::vector<ProfSlot> g_prof;
 static bool g_prof_on = false;
 static std::mutex g_prof_mu;
@@ -56,10 +56,10 @@ void prof_begin() {
 
 struct ProfScope {
     bool on; hipStream_t s; size_t idx;
-    ProfScope(const char* name, double flops, hipStream_t st) : on(g_prof_on), s(st), idx(0) {
+    ProfScope(const char* name, double flops, hipStream_t st, const char* tag = "") : on(g_prof_on), s(st), idx(0) {
         if (!on) return;
         std::lock_guard<std::mutex> lk(g_prof_mu);
-        ProfSlot sl; sl.name = name; sl.flops = flops;
+        ProfSlot sl; sl.name = name; sl.tag = tag; sl.flops = flops;
         if (hipEventCreate(&sl.e0) != hipSuccess || hipEventCreate(&sl.e1) != hipSuccess) { on = false; return; }
         (void)hipEventRecord(sl.e0, s);
         g_prof.push_back(sl);
@@ -78,16 +78,23 @@ std::string prof_end() {
     g_prof_on = false;
     struct Agg { long n = 0; double ms = 0, flops = 0; };
     std::map<std::string, Agg> agg;
+    std::string detail;
     for (auto& sl : g_prof) {
         (void)hipEventSynchronize(sl.e1);
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, sl.e0, sl.e1) == hipSuccess) {
             Agg& a = agg[sl.name]; a.n += 1; a.ms += ms; a.flops += sl.flops;
+            if (getenv("WUN_PROFILE_DETAIL") != nullptr) {
+                char buf[512];
+                snprintf(buf, sizeof(buf), "%s{\"name\": \"%s\", \"tag\": \"%s\", \"ms\": %.6f, \"flops\": %.6e}",
+                         detail.empty() ? "" : ", ", sl.name.c_str(), sl.tag.c_str(), ms, sl.flops);
+                detail += buf;
+            }
         }
         (void)hipEventDestroy(sl.e0); (void)hipEventDestroy(sl.e1);
     }
     g_prof.clear();
-    std::string out = "{\"kernels\": [";
+    std::string out = "{\"launches\": [" + detail + "], \"kernels\": [";
     bool first = true;
     for (auto& kv : agg) {
         char buf[512];
@@ -701,6 +708,14 @@ static hipError_t conv_launch_t(ConvArgs a, int variant, float* part, long long 
 #endif
     int ksplit, cps;
     conv_splitk(a, variant, (part != nullptr && !phase2) ? part_cap : 0, ksplit, cps);
+    if (a.force_ksplit > 0 && !phase2) {                         // autotuned choice
+        const int CKC = a.loader == LOADER_DEINT ? CK / 2 : CK;
+        const int nchunks = (a.C0 + a.C1 + CKC - 1) / CKC;
+        int want = a.force_ksplit > nchunks ? nchunks : a.force_ksplit;
+        if (part == nullptr) want = 1;
+        cps = (nchunks + want - 1) / want;
+        ksplit = (nchunks + cps - 1) / cps;
+    }
     a.cps = cps;
     a.part = ksplit > 1 ? part : nullptr;
     const long long grid = (long long)nTT * nNT * a.B * ksplit;
@@ -708,7 +723,11 @@ static hipError_t conv_launch_t(ConvArgs a, int variant, float* part, long long 
     char nm[64];
     snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %s>", MT, NW, WT, WN, CK, VECW ? "true" : "false");
     {
-        ProfScope ps(nm, conv_flops(a), s);
+        char tag[160];
+        snprintf(tag, sizeof(tag), "C=%d N=%d T=%d K=%d ld=%d B=%d ks=%d ph2=%d acc=%d os=%d grid=%lld", a.C0 + a.C1, a.N,
+                 a.Tout, a.KW, a.loader, a.B, ksplit, (a.flags & F_PHASE2) ? 1 : 0, (a.flags & F_ACCUM) ? 1 : 0,
+                 a.ostride, grid);
+        ProfScope ps(nm, conv_flops(a), s, tag);
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_launch, s, a, nTT, nNT, J, XP, WP);
     }
     hipError_t e = hipGetLastError();
@@ -718,6 +737,37 @@ static hipError_t conv_launch_t(ConvArgs a, int variant, float* part, long long 
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, ksplit);
     return hipGetLastError();
+}
+
+// Candidate (tile variant, split-K) choices for the autotuner.  Returns the number written.
+int conv_list_candidates(const ConvArgs& a, long long part_cap, ConvChoice* out, int maxn) {
+    int n = 0;
+    const int Ctot = a.C0 + a.C1;
+    const bool phase2 = (a.flags & F_PHASE2) != 0;
+    if ((a.N & 3) != 0) return 0;                                    // scalar-weight fallback: fixed menu
+    const int nvar = (int)(sizeof(kConvVariants) / sizeof(kConvVariants[0]));
+    static const int ks_menu[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48};
+    for (int v = 0; v < nvar && n < maxn; ++v) {
+        const ConvVariant& cv = kConvVariants[v];
+        if ((Ctot <= 4) != (cv.CK == 4)) continue;
+        if (phase2 && !(cv.WN == 1 && (cv.NW % 2) == 0)) continue;
+        const int TT = cv.WT * cv.MT * 16;
+        const int NT = phase2 ? cv.WN * cv.NW * 8 : cv.WN * cv.NW * 16;   // channels per workgroup
+        if (TT > 16 && TT >= 2 * a.Tout) continue;                    // mostly padding in time
+        const int padded = ((a.N + NT - 1) / NT) * NT;
+        if (padded * 3 > a.N * 4 + 48) continue;                      // > ~33 % padded columns
+        if (conv_lds_bytes(a, v) > 150 * 1024) continue;
+        const int CKC = a.loader == LOADER_DEINT ? cv.CK / 2 : cv.CK;
+        const int nchunks = (Ctot + CKC - 1) / CKC;
+        const long long natural = (long long)((a.Tout + TT - 1) / TT) * ((a.N + NT - 1) / NT) * a.B;
+        const long long per = (long long)a.B * a.N * ((a.Tout + 3) & ~3);
+        for (unsigned i = 0; i < sizeof(ks_menu) / sizeof(ks_menu[0]) && n < maxn; ++i) {
+            const int ks = ks_menu[i];
+            if (ks > 1 && (phase2 || ks > nchunks || natural * ks > 6144 || (long long)ks * per > part_cap)) break;
+            out[n].variant = v; out[n].ksplit = ks; ++n;
+        }
+    }
+    return n;
 }
 
 // Vector (16-byte) paths need aligned bases / pitches; everything the plan allocates is.
@@ -740,6 +790,7 @@ hipError_t launch_conv(const ConvArgs& a_in, float* part, long long part_cap, hi
     if (const char* e = getenv("WUN_NOVEC")) if (atoi(e)) a.flags &= ~F_VEC4;
 #endif
     int v = (a.flags & F_PHASE2) ? conv_pick_variant_phase2(a) : conv_pick_variant(a);
+    if (a.force_variant > 0 && vecw) v = a.force_variant - 1;
 #ifdef WUN_ABLATION
     if (const char* e = getenv("WUN_VARIANT")) v = atoi(e);
 #endif
@@ -1027,7 +1078,7 @@ static WgradGeom wgrad_geom(const WgradArgs& a) {
         const int padded = ((a.N + nw * 16 - 1) / (nw * 16)) * nw * 16;
         if (padded < bestpad) { bestpad = padded; bestnw = nw; }
     }
-    g.NW = bestnw;
+    g.NW = (a.force_nw >= 1 && a.force_nw <= 3) ? a.force_nw : bestnw;
     int tk = (a.Tq + 3) & ~3;
     if (tk > 128) tk = 128;
     if (tk < 4) tk = 4;
@@ -1041,6 +1092,7 @@ static WgradGeom wgrad_geom(const WgradArgs& a) {
     g.ZP = fit_pitch(tk, 2);
     // the M-group (rows of 4*MTW*16 (cin,tap) pairs) must stage within WUN_WG_XIT vectors/thread
     int mtw = mtiles <= 4 ? 1 : (mtiles <= 8 ? 2 : 6);
+    if (a.force_mtw == 1 || a.force_mtw == 2 || a.force_mtw == 4 || a.force_mtw == 6) mtw = a.force_mtw;
     for (;;) {
         const int MG = 4 * mtw * 16;
         int nch = (MG + a.KW - 2) / a.KW + 1;
@@ -1056,6 +1108,11 @@ static WgradGeom wgrad_geom(const WgradArgs& a) {
     g.ONESP = (tk + 15) & ~15;
     g.lds = sizeof(float) * ((size_t)g.ONESP + (size_t)g.nChMax * (deint ? 2 : 1) * g.XP + (size_t)NG * g.ZP);
     return g;
+}
+
+int wgrad_max_units(const WgradArgs& a) {
+    WgradGeom g = wgrad_geom(a);
+    return a.B * ((a.Tq + g.TK - 1) / g.TK);
 }
 
 int wgrad_pick_nsplit(const WgradArgs& a) {
@@ -1091,7 +1148,10 @@ static hipError_t wgrad_launch_t(WgradArgs a, const WgradGeom& g, hipStream_t s)
     const long long grid = (long long)g.nMG * g.nNG * a.nsplit;
     char nm[64];
     snprintf(nm, sizeof(nm), "wgrad_mfma_kernel<%d, %d>", MTW, NW);
-    ProfScope ps(nm, 2.0 * a.KW * (double)(a.C0 + a.C1) * a.N * (double)a.Tq * a.B, s);
+    char tag[160];
+    snprintf(tag, sizeof(tag), "C=%d N=%d T=%d K=%d ld=%d B=%d nsplit=%d grid=%lld", a.C0 + a.C1, a.N, a.Tq, a.KW,
+             a.loader, a.B, a.nsplit, grid);
+    ProfScope ps(nm, 2.0 * a.KW * (double)(a.C0 + a.C1) * a.N * (double)a.Tq * a.B, s, tag);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), g.lds, s, a, g.nMG, g.nNG, g.TK, g.XP,
                        g.ZP, g.nChMax, g.ONESP, g.XW4);
     return hipGetLastError();

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -114,6 +115,13 @@ struct wun_plan {
     // second HIP stream: independent launches (weight gradients vs the input-gradient chain;
     // skip-window convs vs the decimating convs) run concurrently so that one kernel's tail and
     // epilogue overlap another kernel's MFMA phase
+    // autotuner state: per-launch choices in launch order (forward / backward), filled by wun_plan_tune
+    mutable int tune_mode = 0;                  // 0 = heuristics, 1 = measuring, 2 = tuned
+    mutable std::vector<ConvChoice> conv_fwd, conv_bwd;
+    mutable std::vector<WgradChoice> wg_bwd;
+    mutable size_t ci = 0, wi = 0;
+    mutable bool in_bwd = false;
+    mutable hipEvent_t tev0 = nullptr, tev1 = nullptr;
     mutable hipStream_t side = nullptr;
     mutable std::vector<hipEvent_t> events;
     mutable size_t ev_next = 0;
@@ -362,6 +370,7 @@ extern "C" void wun_plan_destroy(wun_plan* p) {
     if (!p) return;
     if (p->dev_wt) (void)hipFree(p->dev_wt);
     for (auto e : p->events) (void)hipEventDestroy(e);
+    if (p->tev0) { (void)hipEventDestroy(p->tev0); (void)hipEventDestroy(p->tev1); }
     if (p->side) (void)hipStreamDestroy(p->side);
     delete p;
 }
@@ -465,6 +474,56 @@ static int stream_dep(const wun_plan* p, hipStream_t from, hipStream_t to) {
     return WUN_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// autotuned dispatch: every conv / wgrad launch of a step has a fixed position in the launch
+// order; wun_plan_tune measures candidate (tile variant, split-K) / (geometry, split count)
+// choices for each position on the real buffers and caches the fastest.
+// ---------------------------------------------------------------------------------------
+static float time_launch(const wun_plan* p, hipStream_t s, const std::function<hipError_t()>& fn) {
+    if (fn() != hipSuccess) { (void)hipGetLastError(); return 1e30f; }      // warm-up / validity
+    float best = 1e30f;
+    for (int r = 0; r < 2; ++r) {
+        (void)hipEventRecord(p->tev0, s);
+        if (fn() != hipSuccess) { (void)hipGetLastError(); return 1e30f; }
+        (void)hipEventRecord(p->tev1, s);
+        if (hipEventSynchronize(p->tev1) != hipSuccess) return 1e30f;
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, p->tev0, p->tev1);
+        if (ms < best) best = ms;
+    }
+    return best;
+}
+
+static hipError_t conv_dispatch(const wun_plan* p, ConvArgs a, float* part, long long cap, hipStream_t s) {
+    std::vector<ConvChoice>& vec = p->in_bwd ? p->conv_bwd : p->conv_fwd;
+    const size_t idx = p->ci++;
+    if (p->tune_mode == 1) {
+        if (vec.size() <= idx) vec.resize(idx + 1, ConvChoice{-1, 0});
+        ConvChoice cands[96];
+        const int n = conv_list_candidates(a, part ? cap : 0, cands, 96);
+        // the heuristic choice is the baseline; a candidate has to beat it by > 2 %
+        float best = time_launch(p, s, [&]() { return launch_conv(a, part, cap, s); });
+        const float base = best;
+        ConvChoice bc{-1, 0};
+        for (int i = 0; i < n; ++i) {
+            ConvArgs b = a;
+            b.force_variant = cands[i].variant + 1; b.force_ksplit = cands[i].ksplit;
+            const float ms = time_launch(p, s, [&]() { return launch_conv(b, part, cap, s); });
+            if (ms < best * 0.98f) { best = ms; bc = cands[i]; }
+        }
+        vec[idx] = bc;
+        if (getenv("WUN_TUNE_LOG"))
+            fprintf(stderr, "[tune conv %s#%zu] C=%d N=%d T=%d K=%d ld=%d ph2=%d cands=%d base %.3f ms -> v=%d ks=%d %.3f ms\n",
+                    p->in_bwd ? "bwd" : "fwd", idx, a.C0 + a.C1, a.N, a.Tout, a.KW, a.loader, (a.flags & F_PHASE2) ? 1 : 0, n,
+                    base, bc.variant, bc.ksplit, best);
+    }
+    if (p->tune_mode >= 1 && idx < vec.size() && vec[idx].variant >= 0) {
+        a.force_variant = vec[idx].variant + 1; a.force_ksplit = vec[idx].ksplit;
+    }
+    return launch_conv(a, part, cap, s);
+}
+
 // ---------------------------------------------------------------------------------------
 // forward: get_output (UnetAudioSeparator.py:85-144)
 // ---------------------------------------------------------------------------------------
@@ -477,7 +536,8 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
     const int padD = same ? (Kd - 1) / 2 : 0, padU = same ? (Ku - 1) / 2 : 0;
     int rc0;
     if ((rc0 = side_init(p))) return rc0;
-    hipStream_t s2 = (p->side && !g_profiling) ? p->side : s;   // side stream (skip-window convs)
+    p->ci = 0; p->in_bwd = false;
+    hipStream_t s2 = (p->side && !g_profiling && p->tune_mode != 1) ? p->side : s;   // side stream (skip-window convs)
     bool side_used = false;
 
     HIP_TRY(launch_btc_to_ncw(mix_btc, ws + p->mix_ncw.off, p->B, p->Tin, p->C, p->mix_ncw.pitch, s));
@@ -493,7 +553,7 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
             a.KW = Kd; a.N = a.N0 = d.cout; a.Tout = d.t_conv; a.flags = F_LRELU;
             set_dst0(a, ws, p->skip[i], 0, nullptr);
             a.dec = ws + p->dec[i].off; a.decbs = p->dec[i].bs; a.decpitch = p->dec[i].pitch;
-            HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
+            HIP_TRY(conv_dispatch(p, a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
         } else {
             // x (written on `s`) is ready for both convs of this level: the side stream may start
             if ((rc0 = stream_dep(p, s, s2))) return rc0;
@@ -504,7 +564,7 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
             a.Tin = d.t_in; a.shift = 0; a.W = params + cl.woff; a.bias = params + cl.boff;
             a.KW = Kd; a.N = a.N0 = d.cout; a.Tout = d.t_dec; a.flags = F_LRELU;
             set_dst0(a, ws, p->dec[i], 0, nullptr);
-            HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
+            HIP_TRY(conv_dispatch(p, a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
             // full-rate conv only over the window the skip connection crops (Utils.py:104-123);
             // independent of the decimating conv -> side stream, own half of the split-K scratch
             ConvArgs b = conv_base(p);
@@ -512,7 +572,7 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
             b.Tin = d.tc + Kd - 1; b.shift = 0; b.W = params + cl.woff; b.bias = params + cl.boff;
             b.KW = Kd; b.N = b.N0 = d.cout; b.Tout = d.tc; b.flags = F_LRELU;
             set_dst0(b, ws, p->skip[i], 0, nullptr);
-            HIP_TRY(launch_conv(b, ws + p->conv_part_off + p->conv_part_floats / 2, p->conv_part_floats / 2, s2));
+            HIP_TRY(conv_dispatch(p, b, ws + p->conv_part_off + p->conv_part_floats / 2, p->conv_part_floats / 2, s2));
             side_used = side_used || (s2 != s);
         }
         x = &p->dec[i];
@@ -523,7 +583,7 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
         a.Tin = p->t_b_in; a.shift = padD; a.W = params + p->bott.woff; a.bias = params + p->bott.boff;
         a.KW = Kd; a.N = a.N0 = p->c_b; a.Tout = p->t_b; a.flags = F_LRELU;
         set_dst0(a, ws, p->bott_out, 0, nullptr);
-        HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
+        HIP_TRY(conv_dispatch(p, a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
     }
     if (side_used && (rc0 = stream_dep(p, s2, s))) return rc0;     // the up path reads the skip windows
     const Buf* cur = &p->bott_out;
@@ -542,7 +602,7 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
         a.Tin = u.t_up; a.shift = padU; a.W = params + p->up[j].woff; a.bias = params + p->up[j].boff;
         a.KW = Ku; a.N = a.N0 = u.cout; a.Tout = u.t_conv; a.flags = F_LRELU;
         set_dst0(a, ws, p->upo[j], 0, nullptr);
-        HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
+        HIP_TRY(conv_dispatch(p, a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
         cur = &p->upo[j];
     }
     HeadArgs h = head_args(p, params, ws, outputs, training);
@@ -563,13 +623,55 @@ static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const Conv
         if (rcd) return rcd;
     }
     const long long blk = (long long)cl.KW * cl.Cin * cl.Cout + cl.Cout;
+    float* partial = ws + p->partial_off;
     int total = 0;
     for (int i = 0; i < nparts; ++i) {
+        const size_t idx = p->wi++;
         parts[i].nsplit = wgrad_pick_nsplit(parts[i]);
+        if (p->tune_mode == 1) {
+            if (p->wg_bwd.size() <= idx) p->wg_bwd.resize(idx + 1, WgradChoice{0, 0, 0});
+            // candidates: geometry x split count, each timed together with its split reduction
+            const long long cap_splits = p->partial_floats / blk / nparts;
+            auto run = [&](const WgradArgs& w) -> hipError_t {
+                WgradArgs q = w;
+                q.out = partial; q.split_stride = blk;
+                hipError_t e = launch_wgrad(q, s);
+                if (e != hipSuccess || q.nsplit == 1) return e;
+                return launch_reduce(partial, blk, q.nsplit, grads + cl.woff, blk, s);
+            };
+            float best = time_launch(p, s, [&]() { return run(parts[i]); });
+            const float base = best;
+            WgradChoice bc{0, 0, 0};
+            static const int mtws[] = {6, 4, 2, 1};
+            for (int mi = 0; mi < 4; ++mi)
+                for (int nw = 3; nw >= 1; --nw) {
+                    WgradArgs g = parts[i];
+                    g.force_mtw = mtws[mi]; g.force_nw = nw;
+                    const int units = wgrad_max_units(g);
+                    const int base = wgrad_pick_nsplit(g);
+                    const int opts[4] = {base, base / 2, base * 2, base / 4};
+                    for (int oi = 0; oi < 4; ++oi) {
+                        int ns = opts[oi];
+                        if (ns < 1 || ns > units || ns > cap_splits) continue;
+                        if (oi > 0 && ns == opts[0]) continue;
+                        g.nsplit = ns;
+                        const float ms = time_launch(p, s, [&]() { return run(g); });
+                        if (ms < best * 0.98f) { best = ms; bc = WgradChoice{g.force_mtw, g.force_nw, ns}; }
+                    }
+                }
+            p->wg_bwd[idx] = bc;
+            if (getenv("WUN_TUNE_LOG"))
+                fprintf(stderr, "[tune wgrad #%zu] C=%d N=%d T=%d K=%d ld=%d base(ns=%d) %.3f ms -> mtw=%d nw=%d ns=%d %.3f ms\n",
+                        idx, parts[i].C0 + parts[i].C1, parts[i].N, parts[i].Tq, parts[i].KW, parts[i].loader,
+                        parts[i].nsplit, base, bc.mtw, bc.nw, bc.nsplit, best);
+        }
+        if (p->tune_mode >= 1 && idx < p->wg_bwd.size() && p->wg_bwd[idx].nsplit > 0) {
+            parts[i].force_mtw = p->wg_bwd[idx].mtw; parts[i].force_nw = p->wg_bwd[idx].nw;
+            parts[i].nsplit = p->wg_bwd[idx].nsplit;
+        }
         total += parts[i].nsplit;
     }
     if ((long long)total * blk > p->partial_floats) return fail(WUN_ERR_INVALID, "internal: wgrad partial buffer too small");
-    float* partial = ws + p->partial_off;
     if (total == 1) {
         parts[0].out = grads + cl.woff; parts[0].split_stride = blk;
         HIP_TRY(launch_wgrad(parts[0], s));
@@ -623,7 +725,8 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
     const int F = p->cfg.num_initial_filters, C = p->C;
     int rc;
     if ((rc = side_init(p))) return rc;
-    hipStream_t s2 = (p->side && !g_profiling) ? p->side : s;   // side stream: weight gradients + their reductions
+    p->ci = 0; p->wi = 0; p->in_bwd = true;
+    hipStream_t s2 = (p->side && !g_profiling && p->tune_mode != 1) ? p->side : s;   // side stream: weight gradients + their reductions
 
     HIP_TRY(launch_make_wt(params, ws, p->dev_wt, (int)p->wt.size(), p->wt_max, s));
 
@@ -667,7 +770,7 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
             a.N = u.c_skip + u.c_cur; a.N0 = u.c_skip; a.Tout = u.t_up;
             set_dst0(a, ws, p->dz_skip[i], 0, &p->skip[i]);
             set_dst1(a, ws, p->d_ups[j], 0, nullptr);
-            HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
+            HIP_TRY(conv_dispatch(p, a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
         }
         {
             const Buf& prev = (j == 0) ? p->bott_out : p->upo[j - 1];
@@ -702,7 +805,7 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
         } else {
             set_dst0(a, ws, p->dz_dec[L - 1], 0, &p->dec[L - 1]);
         }
-        HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
+        HIP_TRY(conv_dispatch(p, a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
     }
 
     // ---- down path ----
@@ -724,7 +827,7 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
                 a.N = a.N0 = d.cin; a.Tout = d.t_in;
                 set_dst0(a, ws, p->dz_skip[i - 1], 0, &p->skip[i - 1]);
                 a.ostride = 2; a.flags = F_ACCUM;
-                HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
+                HIP_TRY(conv_dispatch(p, a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
             }
         } else {
             WgradArgs w[2];
@@ -747,8 +850,8 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
                 f.Tin = d.t_dec; f.KW = cl.J0; f.kw_full = Kd; f.shift = cl.J0 - 1; f.W = ws + cl.wt_ph2;
                 f.N = f.N0 = d.cin; f.Tout = (d.t_in + 1) / 2; f.Tlim = d.t_in; f.flags = F_PHASE2;
                 set_dst0(f, ws, p->dz_dec[i - 1], 0, &p->dec[i - 1]);
-                if ((d.cin & 3) == 0 && conv_natural_wgs_phase2(f) >= 256) {
-                    HIP_TRY(launch_conv(f, ws + p->conv_part_off, p->conv_part_floats / 2, s));
+                if ((d.cin & 3) == 0 && f.Tout >= 256 && conv_natural_wgs_phase2(f) >= 256) {
+                    HIP_TRY(conv_dispatch(p, f, ws + p->conv_part_off, p->conv_part_floats / 2, s));
                 } else {
                     for (int ph = 0; ph < 2; ++ph) {
                         ConvArgs a = conv_base(p);
@@ -757,7 +860,7 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
                         a.N = a.N0 = d.cin; a.Tout = (d.t_in - ph + 1) / 2;
                         set_dst0(a, ws, p->dz_dec[i - 1], ph, &p->dec[i - 1]);
                         a.ostride = 2;
-                        HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
+                        HIP_TRY(conv_dispatch(p, a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
                     }
                 }
                 ConvArgs a = conv_base(p);
@@ -766,13 +869,29 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
                 a.N = a.N0 = d.cin; a.Tout = d.tc + Kd - 1;
                 set_dst0(a, ws, p->dz_dec[i - 1], d.cs, &p->dec[i - 1]);
                 a.flags = F_ACCUM;
-                HIP_TRY(launch_conv(a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
+                HIP_TRY(conv_dispatch(p, a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
             }
         }
     }
     if ((rc = stream_dep(p, s2, s))) return rc;      // all gradients are complete w.r.t. `stream`
     if ((rc = sig.ready(0, s))) return rc;           // any bucket not yet signalled (e.g. single-stream mode)
     return WUN_OK;
+}
+
+extern "C" int wun_plan_tune(const wun_plan* p, const float* params, const float* mix_btc, float* ws,
+                             float* outputs, const float* targets, float* grads, float* loss, void* stream) {
+    if (!p) return fail(WUN_ERR_INVALID, "null argument");
+    if (!p->tev0) {
+        HIP_TRY(hipEventCreate(&p->tev0));
+        HIP_TRY(hipEventCreate(&p->tev1));
+    }
+    p->conv_fwd.clear(); p->conv_bwd.clear(); p->wg_bwd.clear();
+    p->tune_mode = 1;
+    int rc = wun_forward(p, params, mix_btc, ws, outputs, 1, stream);
+    if (rc == WUN_OK) rc = wun_loss_backward(p, params, mix_btc, ws, outputs, targets, grads, loss, stream);
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    p->tune_mode = rc == WUN_OK ? 2 : 0;
+    return rc;
 }
 
 extern "C" int wun_adam_step(const wun_plan* p, float* params, const float* grads, float* m, float* v,

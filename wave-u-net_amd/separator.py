@@ -229,6 +229,24 @@ class UnetAudioSeparator(object):
             self.grads.data_ptr(), loss.data_ptr(), self._stream(), starts, events, nb))
         return loss
 
+    def tune(self, input, targets):
+        """Autotune the kernels of this (batch, length) plan on real buffers: one forward +
+        backward with per-launch timing of candidate tilings (wun_plan_tune).  Returns the loss."""
+        dev = self._dev()
+        mix = torch.as_tensor(input).to(device=dev, dtype=torch.float32).contiguous()
+        self.get_output(mix, True)                         # allocates plan / workspace / outputs
+        if isinstance(targets, dict):
+            tg = torch.stack([torch.as_tensor(targets[n]).to(dev, torch.float32) for n in self.source_names])
+        else:
+            tg = targets.to(dev, torch.float32)
+        tg = tg.contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        _lib.check(self._lib.wun_plan_tune(
+            self._active.handle, self.params.data_ptr(), mix.data_ptr(), self._ws[self._last_key].data_ptr(),
+            self._outs[self._last_key].data_ptr(), tg.data_ptr(), self.grads.data_ptr(), loss.data_ptr(),
+            self._stream()))
+        return loss
+
     def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
         """tf.train.AdamOptimizer(learning_rate=lr) update (Training.py:77) + global_step += 1."""
         self.global_step += 1

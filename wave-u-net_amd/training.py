@@ -66,6 +66,11 @@ class Trainer(object):
             self.reducer = GradAllReducer(plan.tensors, plan.info.arena_floats, bucket_mib)
         self.lr = model_config["init_sup_sep_lr"]
 
+    def tune(self, mix, targets):
+        """One-off kernel autotuning on a real batch (skipped with WUN_NO_TUNE=1)."""
+        if os.environ.get("WUN_NO_TUNE") is None:
+            self.sep.tune(mix, targets)
+
     def step(self, mix, targets):
         self.sep.get_output(mix, True)
         if self.overlap:
@@ -102,6 +107,7 @@ def train(model_config, experiment_id, load_model=None, batch_source=None, log_e
     if tr.rank == 0:
         os.makedirs(log_dir, exist_ok=True)
     log = open(os.path.join(log_dir, "train.jsonl"), "a") if tr.rank == 0 else None
+    tr.tune(*batch_source())
     t0 = time.time()
     for it in range(model_config["epoch_it"]):                      # Training.py:103-109
         mix, targets = batch_source()
