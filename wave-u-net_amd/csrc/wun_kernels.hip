@@ -586,6 +586,15 @@ static const ConvVariant kConvVariants[] = {
     {1, 2, 1, 4, 8},                                                      // 12    :  16 x 128
     {4, 2, 4, 1, 4}, {1, 2, 4, 1, 4},                                     // 13..14: 1-/2-channel audio input
     {2, 6, 4, 1, 8}, {4, 6, 4, 1, 8},                                     // 15..16: 128/256 x 96 (fused two-phase dgrad)
+    // non-power-of-two tile heights: let the autotuner land the workgroup count on a multiple of
+    // the 256 CUs (e.g. T = 9203: 96 tiles of 192 rows x 16 excerpts = 6 workgroups per CU)
+    {3, 2, 4, 1, 8}, {3, 3, 4, 1, 8}, {3, 4, 4, 1, 8}, {3, 5, 4, 1, 8},   // 17..20: 192 x 32/48/64/80
+    {3, 6, 4, 1, 8},                                                      // 21    : 192 x 96
+    {5, 2, 4, 1, 8}, {5, 3, 4, 1, 8},                                     // 22..23: 320 x 32/48
+    {6, 2, 4, 1, 8}, {6, 3, 4, 1, 8},                                     // 24..25: 384 x 32/48
+    // 4-channel chunks for stride-1 launches: half the LDS weight slab -> 3+ workgroups per CU
+    {4, 3, 4, 1, 4}, {2, 3, 4, 1, 4}, {3, 3, 4, 1, 4}, {2, 2, 4, 1, 4}, {3, 2, 4, 1, 4},   // 26..30
+    {4, 5, 4, 1, 4}, {3, 5, 4, 1, 4}, {2, 5, 4, 1, 4},                                    // 31..33
 };
 
 static inline int conv_J(const ConvArgs& a) { return a.loader == LOADER_DEINT ? (a.KW + 1) / 2 : a.KW; }
@@ -749,7 +758,8 @@ int conv_list_candidates(const ConvArgs& a, long long part_cap, ConvChoice* out,
     static const int ks_menu[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48};
     for (int v = 0; v < nvar && n < maxn; ++v) {
         const ConvVariant& cv = kConvVariants[v];
-        if ((Ctot <= 4) != (cv.CK == 4)) continue;
+        if (Ctot <= 4 && cv.CK != 4) continue;
+        if (Ctot > 4 && cv.CK == 4 && (a.loader == LOADER_DEINT || phase2 || v < 26)) continue;
         if (phase2 && !(cv.WN == 1 && (cv.NW % 2) == 0)) continue;
         const int TT = cv.WT * cv.MT * 16;
         const int NT = phase2 ? cv.WN * cv.NW * 8 : cv.WN * cv.NW * 16;   // channels per workgroup
@@ -817,6 +827,12 @@ hipError_t launch_conv(const ConvArgs& a_in, float* part, long long part_cap, hi
         WUN_CV(12, 1, 2, 1, 4, 8)
         WUN_CV(13, 4, 2, 4, 1, 4) WUN_CV(14, 1, 2, 4, 1, 4)
         WUN_CV(15, 2, 6, 4, 1, 8) WUN_CV(16, 4, 6, 4, 1, 8)
+        WUN_CV(17, 3, 2, 4, 1, 8) WUN_CV(18, 3, 3, 4, 1, 8) WUN_CV(19, 3, 4, 4, 1, 8) WUN_CV(20, 3, 5, 4, 1, 8)
+        WUN_CV(21, 3, 6, 4, 1, 8)
+        WUN_CV(22, 5, 2, 4, 1, 8) WUN_CV(23, 5, 3, 4, 1, 8)
+        WUN_CV(24, 6, 2, 4, 1, 8) WUN_CV(25, 6, 3, 4, 1, 8)
+        WUN_CV(26, 4, 3, 4, 1, 4) WUN_CV(27, 2, 3, 4, 1, 4) WUN_CV(28, 3, 3, 4, 1, 4) WUN_CV(29, 2, 2, 4, 1, 4)
+        WUN_CV(30, 3, 2, 4, 1, 4) WUN_CV(31, 4, 5, 4, 1, 4) WUN_CV(32, 3, 5, 4, 1, 4) WUN_CV(33, 2, 5, 4, 1, 4)
         default: return hipErrorInvalidValue;
     }
 #undef WUN_CV
@@ -1024,22 +1040,42 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a, int nMG
 #pragma unroll
                 for (int n = 0; n < NW; ++n) bv[n] = Zs[(n * 16 + li) * ZP + 4 * st + lg];
             };
-            auto mm = [&](const float (&av)[MTW], const float (&bv)[NW]) {
+            // same order as the conv kernel: first MFMA, LDS reads of the next k-step, the rest
+            auto mm_first = [&](const float (&av)[MTW], const float (&bv)[NW]) {
+                acc[0][0] = mfma16(av[0], bv[0], acc[0][0]);
+            };
+            auto mm_rest = [&](const float (&av)[MTW], const float (&bv)[NW]) {
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt) {
                     if (mt < nact) {
 #pragma unroll
-                        for (int n = 0; n < NW; ++n) acc[mt][n] = mfma16(av[mt], bv[n], acc[mt][n]);
+                        for (int n = 0; n < NW; ++n)
+                            if (mt + n > 0) acc[mt][n] = mfma16(av[mt], bv[n], acc[mt][n]);
                     }
                 }
             };
+            auto pin = [&]() {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, MTW + NW, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MTW * NW - 1, 0);
+            };
+            const int npair = nsteps >> 1;
             const int last = nsteps - 1;
             ldop(0, a0, b0);
-            for (int st = 0; st < nsteps; st += 2) {
-                ldop(st + 1 < last ? st + 1 : last, a1, b1);
-                mm(a0, b0);
+            int st = 0;
+            for (int it = 0; it < npair; ++it, st += 2) {
+                mm_first(a0, b0);
+                ldop(st + 1, a1, b1);
+                mm_rest(a0, b0);
+                pin();
+                mm_first(a1, b1);
                 ldop(st + 2 < last ? st + 2 : last, a0, b0);
-                if (st + 1 < nsteps) mm(a1, b1);
+                mm_rest(a1, b1);
+                pin();
+            }
+            if (nsteps & 1) {
+                mm_first(a0, b0);
+                mm_rest(a0, b0);
             }
         }
     }
@@ -1078,7 +1114,7 @@ static WgradGeom wgrad_geom(const WgradArgs& a) {
         const int padded = ((a.N + nw * 16 - 1) / (nw * 16)) * nw * 16;
         if (padded < bestpad) { bestpad = padded; bestnw = nw; }
     }
-    g.NW = (a.force_nw >= 1 && a.force_nw <= 3) ? a.force_nw : bestnw;
+    g.NW = (a.force_nw >= 1 && a.force_nw <= 5) ? a.force_nw : bestnw;
     int tk = (a.Tq + 3) & ~3;
     if (tk > 128) tk = 128;
     if (tk < 4) tk = 4;
@@ -1093,6 +1129,7 @@ static WgradGeom wgrad_geom(const WgradArgs& a) {
     // the M-group (rows of 4*MTW*16 (cin,tap) pairs) must stage within WUN_WG_XIT vectors/thread
     int mtw = mtiles <= 4 ? 1 : (mtiles <= 8 ? 2 : 6);
     if (a.force_mtw == 1 || a.force_mtw == 2 || a.force_mtw == 4 || a.force_mtw == 6) mtw = a.force_mtw;
+    if (g.NW > 3 && mtw > 4) mtw = 4;                   // accumulator budget: MTW * NW <= 20 tiles
     for (;;) {
         const int MG = 4 * mtw * 16;
         int nch = (MG + a.KW - 2) / a.KW + 1;
@@ -1172,6 +1209,8 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
     WUN_WG(2, 1) WUN_WG(2, 2) WUN_WG(2, 3)
     WUN_WG(4, 1) WUN_WG(4, 2) WUN_WG(4, 3)
     WUN_WG(6, 1) WUN_WG(6, 2) WUN_WG(6, 3)
+    WUN_WG(1, 4) WUN_WG(2, 4) WUN_WG(4, 4)
+    WUN_WG(1, 5) WUN_WG(2, 5) WUN_WG(4, 5)
 #undef WUN_WG
     return hipErrorInvalidValue;
 }

@@ -500,8 +500,8 @@ static hipError_t conv_dispatch(const wun_plan* p, ConvArgs a, float* part, long
     const size_t idx = p->ci++;
     if (p->tune_mode == 1) {
         if (vec.size() <= idx) vec.resize(idx + 1, ConvChoice{-1, 0});
-        ConvChoice cands[96];
-        const int n = conv_list_candidates(a, part ? cap : 0, cands, 96);
+        ConvChoice cands[160];
+        const int n = conv_list_candidates(a, part ? cap : 0, cands, 160);
         // the heuristic choice is the baseline; a candidate has to beat it by > 2 %
         float best = time_launch(p, s, [&]() { return launch_conv(a, part, cap, s); });
         const float base = best;
@@ -644,7 +644,8 @@ static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const Conv
             WgradChoice bc{0, 0, 0};
             static const int mtws[] = {6, 4, 2, 1};
             for (int mi = 0; mi < 4; ++mi)
-                for (int nw = 3; nw >= 1; --nw) {
+                for (int nw = 5; nw >= 1; --nw) {
+                    if (nw > 3 && (mtws[mi] == 6 || parts[i].N <= 48)) continue;
                     WgradArgs g = parts[i];
                     g.force_mtw = mtws[mi]; g.force_nw = nw;
                     const int units = wgrad_max_units(g);
