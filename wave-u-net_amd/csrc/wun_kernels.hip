@@ -396,7 +396,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
     if (ch_lo < ch_hi && !ab_noload) load_chunk(ch_lo);
     if (ch_lo < ch_hi && !ab_nostore) store_chunk(0);
     __syncthreads();
-    const int half = J / 2;
+#ifndef WUN_STORE_AT
+#define WUN_STORE_AT 2   /* numerator of the tap-loop fraction (over 4) after which the next chunk is written to LDS */
+#endif
+    const int half = (J * WUN_STORE_AT) / 4;
     for (int chunk = ch_lo; chunk < ch_hi; ++chunk) {
         const int cur = ((chunk - ch_lo) & 1) * LB;
         const bool has_next = chunk + 1 < ch_hi;
