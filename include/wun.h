@@ -155,6 +155,11 @@ int wun_op_conv1d_dgrad(const float* dz, const float* w, float* dx, float* wt_sc
                         int batch, int cin, int cout, int k, int t_in, int t_out,
                         int stride, int pad_left, void* stream);
 
+/* Test hook: force the tile variant (index into the kernel's variant table, -1 = automatic) and
+ * split-K factor (0 = automatic) of every following wun_op_conv1d / _dgrad launch, so the parity
+ * tests can reach every tiling.  An infeasible choice makes the launch fail with WUN_ERR_HIP. */
+int wun_op_force_conv_variant(int variant, int ksplit);
+
 /* Lane layout probe of v_mfma_f32_16x16x4_f32: d[16][16] = a[16][4] * b[4][16] (row-major). */
 int wun_op_mfma_probe(const float* a, const float* b, float* d, void* stream);
 

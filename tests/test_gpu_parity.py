@@ -77,6 +77,12 @@ CONV_CASES = [
     (2, 168, 176, 15, 100, 1, 0, False),
     (1, 26, 2, 1, 333, 1, 0, False),
     (1, 96, 120, 15, 260, 2, 0, False),
+    # few output positions per excerpt, several excerpts: batch-folded (FOLD) tiles
+    (16, 40, 72, 15, 39, 1, 0, False),
+    (16, 48, 56, 15, 95, 2, 0, False),
+    (5, 24, 48, 5, 20, 1, 2, True),
+    (16, 96, 96, 15, 110, 1, 0, False),
+    (7, 64, 40, 15, 33, 2, 0, False),
 ]
 
 
@@ -116,6 +122,63 @@ def test_op_conv1d_forward(lib, case):
     got = y.cpu().numpy()
     assert np.isfinite(got).all()
     assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+
+
+FOLD_CASES = [
+    (16, 40, 72, 15, 23, 1, 0, False),      # T_out 9: every excerpt in one tile
+    (16, 48, 96, 15, 95, 2, 0, False),      # stride 2, T_out 41
+    (6, 72, 48, 5, 77, 1, 2, True),         # 'same' padding, T_out 77
+    (16, 24, 64, 15, 151, 1, 0, False),     # T_out 137: two excerpts per 128-row tile
+    (3, 32, 128, 7, 19, 2, 0, False),       # T_out 7 < 9
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", FOLD_CASES, ids=[str(c) for c in FOLD_CASES])
+def test_op_conv1d_every_fold_variant(lib, case):
+    """Forward conv + input gradient through every batch-folded tile variant (34..41) and split-K
+    factor, against the float64 reference."""
+    B, Cin, Cout, K, T, stride, pad, same = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31) + 7)
+    x = rng.uniform(-1, 1, (B, Cin, T)).astype(np.float32)
+    w = (rng.uniform(-1, 1, (K, Cin, Cout)) / np.sqrt(K * Cin)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, Cout).astype(np.float32)
+    t_out = _t_out(T, K, stride, same)
+    dz = rng.uniform(-1, 1, (B, Cout, t_out)).astype(np.float32)
+    ref = _conv_ref(x, w, b, stride, pad, t_out, True)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    need = (t_out - 1) * stride + K - pad
+    xp = F.pad(xt, (pad, max(0, need - T)))
+    yy = F.conv1d(xp, torch.tensor(w, dtype=torch.float64).permute(2, 1, 0), None, stride=stride)[:, :, :t_out]
+    (yy * torch.tensor(dz, dtype=torch.float64)).sum().backward()
+    ref_dx = xt.grad.numpy()
+    dx, dw, db_, dzg = _cuda(x), _cuda(w), _cuda(b), _cuda(dz)
+    wts = torch.empty(2 * K * Cin * Cout, device="cuda")
+    ran = 0
+    try:
+        for variant in range(34, 42):
+            for ks in (1, 3):
+                lib.wun_op_force_conv_variant(variant, ks)
+                y = torch.full((B, Cout, t_out), float("nan"), device="cuda")
+                rc = lib.wun_op_conv1d(dx.data_ptr(), dw.data_ptr(), db_.data_ptr(), y.data_ptr(), B, Cin, Cout,
+                                       K, T, t_out, stride, pad, 1, _stream())
+                if rc != 0:
+                    continue               # segments do not fit this tile's LDS row: rejected, not miscomputed
+                torch.cuda.synchronize()
+                got = y.cpu().numpy()
+                assert np.isfinite(got).all(), (variant, ks)
+                assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (variant, ks)
+                gdx = torch.full((B, Cin, T), float("nan"), device="cuda")
+                _lib.check(lib.wun_op_conv1d_dgrad(dzg.data_ptr(), dw.data_ptr(), gdx.data_ptr(), wts.data_ptr(), B, Cin,
+                                                   Cout, K, T, t_out, stride, pad, _stream()))
+                torch.cuda.synchronize()
+                gd = gdx.cpu().numpy()
+                assert np.isfinite(gd).all(), (variant, ks)
+                assert np.abs(gd - ref_dx).max() <= 1e-4 * max(1.0, np.abs(ref_dx).max()), (variant, ks)
+                ran += 1
+    finally:
+        lib.wun_op_force_conv_variant(-1, 0)
+    assert ran >= 4
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])

@@ -48,6 +48,18 @@ def main():
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * K * Cin * Cout * t_out * B
+    # kernel-only times (HIP events around each heavy launch inside the library)
+    import json
+    lib.wun_profile_begin()
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    buf = C.create_string_buffer(1 << 20)
+    _lib.check(lib.wun_profile_end(buf, len(buf)))
+    for kk in json.loads(buf.value.decode())["kernels"]:
+        if kk["ms"] > 0:
+            print("    %-44s %.3f ms/launch  %.1f TFLOP/s" % (kk["name"], kk["ms"] / kk["launches"],
+                                                              kk["flops"] / kk["ms"] / 1e9))
     print("%s B%d %d->%d K%d T%d s%d | env ABLATE=%s VARIANT=%s NOVEC=%s : %.3f ms  %.1f TFLOP/s" % (
         kind, B, Cin, Cout, K, T, stride, os.environ.get("WUN_ABLATE", "-"), os.environ.get("WUN_VARIANT", "-"),
         os.environ.get("WUN_NOVEC", "-"), ms, flops / ms / 1e9))

@@ -46,6 +46,7 @@ _SIGS = {
     "wun_op_conv1d_wgrad": (C.c_int, [_P, _P, _P, _P, _P] + [C.c_int] * 8 + [_P]),
     "wun_op_conv1d_dgrad": (C.c_int, [_P, _P, _P, _P] + [C.c_int] * 8 + [_P]),
     "wun_op_mfma_probe": (C.c_int, [_P, _P, _P, _P]),
+    "wun_op_force_conv_variant": (C.c_int, [C.c_int, C.c_int]),
     "wun_profile_begin": (C.c_int, []),
     "wun_profile_end": (C.c_int, [C.c_char_p, C.c_int64]),
     "wun_last_error": (C.c_char_p, []),

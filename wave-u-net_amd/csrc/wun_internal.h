@@ -66,14 +66,16 @@ struct WgradArgs {
     int KW;
     int loader;      // DIRECT (SI = 1) / DEINT (SI = 2)
     const float* dz; long long dzbs; int dzpitch; int N; int Tq;
-    float* out; long long split_stride;
+    float* out;      // direct: final [K][Cin][Cout](+bias row) block; else base of the tile-major split partials
+    int direct;      // 1: single split, write the final layout
+    int split_base;  // index of this launch's first split in the partial buffer
     int nsplit; int units_per_split; int nQT; int B;
     int ablate;      // debugging switches (only read when built with -DWUN_ABLATION)
     int force_mtw, force_nw;   // autotuner: geometry overrides (0 = heuristic)
 };
 
 struct ConvChoice { int variant; int ksplit; };
-struct WgradChoice { int mtw, nw, nsplit; };
+struct WgradChoice { int mtw, nw, nsplit[2]; };   // per layer: shared tile geometry, split count per part
 
 struct UpsampleArgs {
     const float* x; long long xbs; int xpitch; int n;     // [B][C][n]
@@ -125,6 +127,10 @@ int wgrad_max_units(const WgradArgs& a);
 
 int  wgrad_pick_nsplit(const WgradArgs& a);
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s);
+void wgrad_resolved_geom(const WgradArgs& a, int& mtw, int& nw);
+long long wgrad_partial_floats(const WgradArgs& a);
+hipError_t launch_wgrad_reduce(const WgradArgs& a, const float* partial, int nsplit, float* out_w, float* out_b,
+                               hipStream_t s);
 hipError_t launch_reduce(const float* partial, long long stride, int nsplit, float* out,
                          long long n, hipStream_t s);
 hipError_t launch_upsample(const UpsampleArgs& a, hipStream_t s);

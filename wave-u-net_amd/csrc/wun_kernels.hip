@@ -119,7 +119,15 @@ std::string prof_end() {
 // them in a fixed order and applies the epilogue.
 #define WUN_JMAX 15
 
-template <int MT, int NW, int WT, int WN, int CK, bool VECW>
+//
+// FOLD variants (deep levels, few output positions per excerpt): the GEMM M axis is the flattened
+// (excerpt, position) index, so one workgroup tile spans several excerpts and every weight slab
+// is fetched once per tile instead of once per excerpt.  The LDS input row then holds one
+// full-length segment per excerpt of the tile; only the staging addresses, the per-lane A-operand
+// offsets and the epilogue's (excerpt, position) decode differ from the plain kernel.
+#define WUN_FOLD_XCAP(TT) (3 * (TT) + 32)      // LDS input-row capacity of a FOLD tile (floats per plane)
+
+template <int MT, int NW, int WT, int WN, int CK, bool VECW, bool FOLD = false>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int nNT, int J,
                                                         int XP, int WP) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -129,9 +137,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
     constexpr int CH = CK / 2;
     // staging trip counts (compile time, sized for J <= WUN_JMAX)
     constexpr int TPR = 256 / CK;                                   // DIRECT: threads per LDS row
-    constexpr int XIT_D = (TT + WUN_JMAX - 1 + TPR - 1) / TPR;
+    constexpr int XIT_D = FOLD ? (WUN_FOLD_XCAP(TT) + TPR - 1) / TPR : (TT + WUN_JMAX - 1 + TPR - 1) / TPR;
     constexpr int TPC = 256 / CH;                                   // DEINT: threads per channel
-    constexpr int XIT_I = (2 * (TT + (WUN_JMAX + 1) / 2 - 1) + TPC - 1) / TPC;
+    constexpr int XIT_I = FOLD ? (2 * WUN_FOLD_XCAP(TT) + TPC - 1) / TPC
+                               : (2 * (TT + (WUN_JMAX + 1) / 2 - 1) + TPC - 1) / TPC;
     constexpr int XIT = XIT_D > XIT_I ? XIT_D : XIT_I;
     constexpr int WIT = (WUN_JMAX * CK * NT4 + 255) / 256;
 
@@ -147,16 +156,24 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
     int bid = blockIdx.x;
     const int nt = bid % nNT; bid /= nNT;
     const int tt = bid % nTT; bid /= nTT;
-    const int b = bid % a.B;
-    const int ksp = bid / a.B;
-    const int q0 = tt * TT, n0 = nt * NT;
+    const int b = FOLD ? (tt * TT) / a.Tout : bid % a.B;      // FOLD: first excerpt of the tile
+    const int ksp = FOLD ? bid : bid / a.B;
+    const int q0 = tt * TT, n0 = nt * NT;                     // FOLD: q0 = first flattened row
+    // FOLD: excerpts touched by this tile and the per-excerpt segment length in the LDS row
+    int fold_nb = 1;
+    const int fold_seg = a.Tout + J - 1;
+    if constexpr (FOLD) {
+        int last = (q0 + TT - 1) / a.Tout;
+        if (last > a.B - 1) last = a.B - 1;
+        fold_nb = last - b + 1;
+    }
     const int wt0 = (wave % WT) * MT * 16;
     const int wn0 = (wave / WT) * NW * 16;
     const int Ctot = a.C0 + a.C1;
     const bool deint = (a.loader == LOADER_DEINT);
     const bool phase2 = (a.flags & F_PHASE2) != 0;      // only launched on WN == 1, even NW variants
     const int n0h = nt * (NT / 2);
-    const int UW = TT + J - 1;
+    const int UW = FOLD ? fold_nb * fold_seg : TT + J - 1;
     const int CKC = deint ? CH : CK;                 // input channels per chunk
     const int nchunks = (Ctot + CKC - 1) / CKC;
     const int ch_lo = ksp * a.cps;
@@ -187,13 +204,19 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
         const int stride_i = deint ? TPC : TPR;
         const int lim = deint ? 2 * UW : UW;
         const int tbase = (deint ? 2 * q0 : q0) - a.shift;
+        const int seglen = deint ? 2 * fold_seg : fold_seg;
 #pragma unroll
         for (int i = 0; i < XIT; ++i) {
             const int u = lr + i * stride_i;
-            const int t = tbase + u;
+            int t = tbase + u, bl = 0;
+            if constexpr (FOLD) { bl = u / seglen; t = u - bl * seglen - a.shift; }
             const bool ok = u < lim && t >= 0 && t < a.Tin;
             int tc = t < 0 ? 0 : t;
             if (tc > a.Tin - 1) tc = a.Tin - 1;
+            if constexpr (FOLD) {
+                if (bl > fold_nb - 1) bl = fold_nb - 1;
+                tc |= bl << 20;                       // excerpt within the tile (Tin < 2^20, checked by the launcher)
+            }
             xt[i] = tc;
             xmask_s |= (ok ? 1u : 0u) << i;
         }
@@ -238,9 +261,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
             const float* p = (!cok || c < a.C0) ? src0b + (long long)(cok ? c : 0) * a.pitch0
                                                 : src1b + (long long)(c - a.C0) * a.pitch1;
             const int nx = deint ? XIT_I : XIT_D;
+            const int bsel = (!cok || c < a.C0) ? (int)a.bs0 : (int)a.bs1;
 #pragma unroll
             for (int i = 0; i < XIT; ++i)
-                if (i < nx) xreg[i] = p[xt[i]];
+                if (i < nx) {
+                    if constexpr (FOLD) xreg[i] = p[(xt[i] >> 20) * bsel + (xt[i] & 0xFFFFF)];
+                    else xreg[i] = p[xt[i]];
+                }
             xmask = cok ? xmask_s : 0u;
         }
         const bool tail = c0 + CKC > Ctot;                // uniform; only the last chunk of odd configs
@@ -305,10 +332,23 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
     // (double-buffered registers, pointer-increment addressing), so LDS latency is covered by
     // the remaining MFMAs.
     constexpr int KS = CK / 4;
+    // FOLD: LDS position (segment of its excerpt + output position) of this lane's A row per M tile
+    int arow[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        arow[m] = 0;
+        if constexpr (FOLD) {
+            const int row = q0 + wt0 + m * 16 + li;
+            int g = row / a.Tout;
+            const int q = row - g * a.Tout;
+            g -= b;
+            arow[m] = g < fold_nb ? g * fold_seg + q : 0;      // rows past the last excerpt: results discarded
+        }
+    }
     const bool skip_last_odd = deint && CK == 8 && (a.KW & 1);     // the odd phase has no tap KW
     auto run_taps = [&](int bufoff, int j_begin, int j_end) {
         if (j_end <= j_begin) return;
-        const float* xa = Xs + bufoff + lg * XP + wt0 + li + j_begin;          // tap j, rows 0..3
+        const float* xa = Xs + bufoff + lg * XP + (FOLD ? 0 : wt0 + li) + j_begin;   // tap j, rows 0..3
         const float* wb = Ws + bufoff + (j_begin * CK + lg) * WP + wn0 + li;
         const int wstep = CK * WP;
         float a0[MT], b0[NW], a1[MT], b1[NW];
@@ -321,7 +361,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
                 return;
             }
 #pragma unroll
-            for (int m = 0; m < MT; ++m) av[m] = x[m * 16];
+            for (int m = 0; m < MT; ++m) av[m] = FOLD ? x[arow[m]] : x[m * 16];
 #pragma unroll
             for (int n = 0; n < NW; ++n) bv[n] = w[n * 16];
         };
@@ -421,7 +461,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const int q = q0 + wt0 + m * 16 + lg * 4;
-                if (q < TP) *reinterpret_cast<f32x4*>(&prow[q]) = acc[m][n];
+                if constexpr (FOLD) {
+                    int g = q / a.Tout, qq = q - g * a.Tout;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (g < a.B) a.part[(((long long)ksp * a.B + g) * a.N + ncol) * TP + qq] = acc[m][n][r];
+                        if (++qq == a.Tout) { qq = 0; ++g; }
+                    }
+                } else {
+                    if (q < TP) *reinterpret_cast<f32x4*>(&prow[q]) = acc[m][n];
+                }
             }
         }
         return;
@@ -506,7 +555,27 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int q = q0 + wt0 + m * 16 + lg * 4;
-            if (vec && q + 3 < a.Tout) {
+            if constexpr (FOLD) {
+                int g = q / a.Tout, qq = q - g * a.Tout;
+                const bool first = ncol < a.N0;
+                const long long colbase = first ? (long long)ncol * a.opitch0 + a.ooff0
+                                                : (long long)(ncol - a.N0) * a.opitch1 + a.ooff1;
+                const long long obs = first ? a.obs0 : a.obs1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (g < a.B) {
+                        float v = acc[m][n][r] + bvv;
+                        if (lrelu) v = fmaxf(0.2f * v, v);
+                        const long long idx = (long long)g * obs + colbase + (long long)qq * a.ostride;
+                        if (msk != nullptr) v *= (msk[idx] > 0.f) ? 1.f : 0.2f;
+                        if (accum) v += dst[idx];
+                        dst[idx] = v;
+                        if (a.dec != nullptr && first && (qq & 1) == 0)
+                            a.dec[(long long)g * a.decbs + (long long)ncol * a.decpitch + (qq >> 1)] = v;
+                    }
+                    if (++qq == a.Tout) { qq = 0; ++g; }
+                }
+            } else if (vec && q + 3 < a.Tout) {
                 f32x4 v = acc[m][n];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -580,7 +649,7 @@ __global__ void conv_splitk_epilogue_kernel(ConvArgs a, int ksplit) {
 }
 
 // variant table -------------------------------------------------------------------------
-struct ConvVariant { int MT, NW, WT, WN, CK; };
+struct ConvVariant { int MT, NW, WT, WN, CK, fold; };
 static const ConvVariant kConvVariants[] = {
     {4, 2, 4, 1, 8}, {4, 3, 4, 1, 8}, {4, 4, 4, 1, 8}, {4, 5, 4, 1, 8},   //  0..3 : 256 x 32/48/64/80
     {2, 2, 4, 1, 8}, {2, 3, 4, 1, 8}, {2, 4, 4, 1, 8}, {2, 5, 4, 1, 8},   //  4..7 : 128 x 32/48/64/80
@@ -598,7 +667,27 @@ static const ConvVariant kConvVariants[] = {
     // 4-channel chunks for stride-1 launches: half the LDS weight slab -> 3+ workgroups per CU
     {4, 3, 4, 1, 4}, {2, 3, 4, 1, 4}, {3, 3, 4, 1, 4}, {2, 2, 4, 1, 4}, {3, 2, 4, 1, 4},   // 26..30
     {4, 5, 4, 1, 4}, {3, 5, 4, 1, 4}, {2, 5, 4, 1, 4},                                    // 31..33
+    // FOLD tiles for the deep levels: M = flattened (excerpt, position)
+    {1, 2, 4, 1, 8, 1}, {1, 3, 4, 1, 8, 1},                               // 34..35:  64 x 32/48
+    {2, 2, 4, 1, 8, 1}, {2, 3, 4, 1, 8, 1},                               // 36..37: 128 x 32/48
+    {2, 3, 2, 2, 8, 1}, {4, 3, 2, 2, 8, 1},                               // 38..39:  64/128 x 96
+    {2, 2, 2, 2, 8, 1}, {4, 2, 2, 2, 8, 1},                               // 40..41:  64/128 x 64
 };
+#define WUN_FIRST_FOLD_VARIANT 34
+
+// can this launch use FOLD variant `v`?  (segments of every excerpt a tile touches must fit the LDS row)
+static bool conv_fold_ok(const ConvArgs& a, int v) {
+    const ConvVariant& cv = kConvVariants[v];
+    if (!cv.fold || (a.flags & F_PHASE2)) return false;
+    const int TT = cv.WT * cv.MT * 16;
+    const int J = a.loader == LOADER_DEINT ? (a.KW + 1) / 2 : a.KW;
+    long long nb = (TT - 1) / a.Tout + 2;
+    if (nb > a.B) nb = a.B;
+    if (nb * (a.Tout + J - 1) > WUN_FOLD_XCAP(TT)) return false;
+    if (a.Tin >= (1 << 20)) return false;
+    const long long span0 = a.bs0 * (long long)a.B, span1 = a.src1 ? a.bs1 * (long long)a.B : 0;
+    return span0 < (1ll << 31) && span1 < (1ll << 31);
+}
 
 static inline int conv_J(const ConvArgs& a) { return a.loader == LOADER_DEINT ? (a.KW + 1) / 2 : a.KW; }
 
@@ -616,6 +705,13 @@ static int pick_nw(int N, const int* cands, int ncand) {
 int conv_pick_variant(const ConvArgs& a) {
     const int Ctot = a.C0 + a.C1;
     if (Ctot <= 4) return a.Tout > 64 ? 13 : 14;
+    if (a.Tout <= 96 && a.B > 1 && (a.N & 3) == 0) {
+        // deep levels: fold the batch into M; 128-row tiles when there are enough rows to fill the chip
+        const int c[2] = {3, 2};
+        const int nw = pick_nw(a.N, c, 2);
+        const int v = ((long long)a.B * a.Tout >= 1024 ? 36 : 34) + (nw == 3 ? 1 : 0);
+        if (conv_fold_ok(a, v)) return v;
+    }
     if (a.Tout <= 16) return 12;
     if (a.Tout <= 32) { const int c[2] = {3, 2}; return pick_nw(a.N, c, 2) == 3 ? 11 : 10; }
     if (a.Tout <= 64) { const int c[2] = {3, 2}; return pick_nw(a.N, c, 2) == 3 ? 9 : 8; }
@@ -654,8 +750,15 @@ static void conv_geom(const ConvArgs& a, int variant, int& TT, int& NT, int& J, 
     TT = v.WT * v.MT * 16;
     NT = v.WN * v.NW * 16;
     J = conv_J(a);
-    XP = fit_pitch(TT + J - 1, 16);
+    XP = fit_pitch(v.fold ? WUN_FOLD_XCAP(TT) : TT + J - 1, 16);
     WP = fit_pitch(NT, 16);
+}
+
+// workgroup tiles along M (per excerpt, or over the flattened batch for FOLD) and the excerpt factor of the grid
+static inline long long conv_mtiles(const ConvArgs& a, int variant, int TT, int& bfac) {
+    if (kConvVariants[variant].fold) { bfac = 1; return ((long long)a.B * a.Tout + TT - 1) / TT; }
+    bfac = a.B;
+    return (a.Tout + TT - 1) / TT;
 }
 
 size_t conv_lds_bytes(const ConvArgs& a, int variant) {
@@ -678,7 +781,8 @@ void conv_splitk(const ConvArgs& a, int variant, long long part_cap_floats, int&
     const int CK = kConvVariants[variant].CK;
     const int CKC = a.loader == LOADER_DEINT ? CK / 2 : CK;
     const int nchunks = (a.C0 + a.C1 + CKC - 1) / CKC;
-    const long long natural = (long long)((a.Tout + TT - 1) / TT) * ((a.N + NT - 1) / NT) * a.B;
+    int bfac;
+    const long long natural = conv_mtiles(a, variant, TT, bfac) * ((a.N + NT - 1) / NT) * bfac;
     ksplit = 1; cps = nchunks;
     if (natural >= 512 || nchunks < 2 || part_cap_floats <= 0) return;
     long long want = (1024 + natural - 1) / natural;
@@ -691,15 +795,17 @@ void conv_splitk(const ConvArgs& a, int variant, long long part_cap_floats, int&
     if (ksplit < 2) { ksplit = 1; cps = nchunks; }
 }
 
-template <int MT, int NW, int WT, int WN, int CK, bool VECW>
+template <int MT, int NW, int WT, int WN, int CK, bool VECW, bool FOLD = false>
 static hipError_t conv_launch_t(ConvArgs a, int variant, float* part, long long part_cap, hipStream_t s) {
     int TT, NT, J, XP, WP;
     conv_geom(a, variant, TT, NT, J, XP, WP);
     const bool phase2 = (a.flags & F_PHASE2) != 0;
-    const int nTT = (a.Tout + TT - 1) / TT;
+    int bfac;
+    const int nTT = (int)conv_mtiles(a, variant, TT, bfac);
     const int nNT = phase2 ? (a.N + NT / 2 - 1) / (NT / 2) : (a.N + NT - 1) / NT;
     const size_t lds = conv_lds_bytes(a, variant);
-    auto kern = conv_mfma_kernel<MT, NW, WT, WN, CK, VECW>;
+    if (FOLD && !conv_fold_ok(a, variant)) return hipErrorInvalidValue;
+    auto kern = conv_mfma_kernel<MT, NW, WT, WN, CK, VECW, FOLD>;
     static size_t lds_allowed = 64 * 1024;
     if (lds > lds_allowed) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -730,10 +836,11 @@ static hipError_t conv_launch_t(ConvArgs a, int variant, float* part, long long 
     }
     a.cps = cps;
     a.part = ksplit > 1 ? part : nullptr;
-    const long long grid = (long long)nTT * nNT * a.B * ksplit;
+    const long long grid = (long long)nTT * nNT * bfac * ksplit;
     if (grid <= 0) return hipSuccess;
     char nm[64];
-    snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %s>", MT, NW, WT, WN, CK, VECW ? "true" : "false");
+    snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %s%s>", MT, NW, WT, WN, CK, VECW ? "true" : "false",
+             FOLD ? ", fold" : "");
     {
         char tag[160];
         snprintf(tag, sizeof(tag), "C=%d N=%d T=%d K=%d ld=%d B=%d ks=%d ph2=%d acc=%d os=%d grid=%lld", a.C0 + a.C1, a.N,
@@ -764,15 +871,18 @@ int conv_list_candidates(const ConvArgs& a, long long part_cap, ConvChoice* out,
         if (Ctot <= 4 && cv.CK != 4) continue;
         if (Ctot > 4 && cv.CK == 4 && (a.loader == LOADER_DEINT || phase2 || v < 26)) continue;
         if (phase2 && !(cv.WN == 1 && (cv.NW % 2) == 0)) continue;
+        if (cv.fold && !conv_fold_ok(a, v)) continue;
         const int TT = cv.WT * cv.MT * 16;
         const int NT = phase2 ? cv.WN * cv.NW * 8 : cv.WN * cv.NW * 16;   // channels per workgroup
-        if (TT > 16 && TT >= 2 * a.Tout) continue;                    // mostly padding in time
+        if (!cv.fold && TT > 16 && TT >= 2 * a.Tout) continue;       // mostly padding in time
+        if (cv.fold && (long long)TT >= 2ll * a.B * a.Tout) continue;
         const int padded = ((a.N + NT - 1) / NT) * NT;
         if (padded * 3 > a.N * 4 + 48) continue;                      // > ~33 % padded columns
         if (conv_lds_bytes(a, v) > 150 * 1024) continue;
         const int CKC = a.loader == LOADER_DEINT ? cv.CK / 2 : cv.CK;
         const int nchunks = (Ctot + CKC - 1) / CKC;
-        const long long natural = (long long)((a.Tout + TT - 1) / TT) * ((a.N + NT - 1) / NT) * a.B;
+        int bfac;
+        const long long natural = conv_mtiles(a, v, TT, bfac) * ((a.N + NT - 1) / NT) * bfac;
         const long long per = (long long)a.B * a.N * ((a.Tout + 3) & ~3);
         for (unsigned i = 0; i < sizeof(ks_menu) / sizeof(ks_menu[0]) && n < maxn; ++i) {
             const int ks = ks_menu[i];
@@ -836,6 +946,10 @@ hipError_t launch_conv(const ConvArgs& a_in, float* part, long long part_cap, hi
         WUN_CV(24, 6, 2, 4, 1, 8) WUN_CV(25, 6, 3, 4, 1, 8)
         WUN_CV(26, 4, 3, 4, 1, 4) WUN_CV(27, 2, 3, 4, 1, 4) WUN_CV(28, 3, 3, 4, 1, 4) WUN_CV(29, 2, 2, 4, 1, 4)
         WUN_CV(30, 3, 2, 4, 1, 4) WUN_CV(31, 4, 5, 4, 1, 4) WUN_CV(32, 3, 5, 4, 1, 4) WUN_CV(33, 2, 5, 4, 1, 4)
+#define WUN_CF(i, MT, NW, WT, WN, CK) case i: return conv_launch_t<MT, NW, WT, WN, CK, true, true>(a, v, part, part_cap, s);
+        WUN_CF(34, 1, 2, 4, 1, 8) WUN_CF(35, 1, 3, 4, 1, 8) WUN_CF(36, 2, 2, 4, 1, 8) WUN_CF(37, 2, 3, 4, 1, 8)
+        WUN_CF(38, 2, 3, 2, 2, 8) WUN_CF(39, 4, 3, 2, 2, 8) WUN_CF(40, 2, 2, 2, 2, 8) WUN_CF(41, 4, 2, 2, 2, 8)
+#undef WUN_CF
         default: return hipErrorInvalidValue;
     }
 #undef WUN_CV
@@ -1036,55 +1150,78 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a, int nMG
         __syncthreads();
         if (u + 1 < u1 && !wb_noload) load_unit(u + 1);
         if (!wb_nomfma) {
-            float a0[MTW], b0[NW], a1[MTW], b1[NW];
-            auto ldop = [&](int st, float (&av)[MTW], float (&bv)[NW]) {
+            // Branch-free MFMA stream over all MTW tiles of the wave (the geometry keeps the ragged
+            // last group's dead tiles few).
+            auto run_unit = [&](auto full_tag) {
+                constexpr bool FULL = decltype(full_tag)::value;
+                float a0[MTW], b0[NW], a1[MTW], b1[NW];
+                auto ldop = [&](int st, float (&av)[MTW], float (&bv)[NW]) {
 #pragma unroll
-                for (int mt = 0; mt < MTW; ++mt) av[mt] = lds[rowoff[mt] + 4 * st + lg];
+                    for (int mt = 0; mt < MTW; ++mt) av[mt] = lds[rowoff[mt] + 4 * st + lg];
 #pragma unroll
-                for (int n = 0; n < NW; ++n) bv[n] = Zs[(n * 16 + li) * ZP + 4 * st + lg];
-            };
-            // same order as the conv kernel: first MFMA, LDS reads of the next k-step, the rest
-            auto mm_first = [&](const float (&av)[MTW], const float (&bv)[NW]) {
-                acc[0][0] = mfma16(av[0], bv[0], acc[0][0]);
-            };
-            auto mm_rest = [&](const float (&av)[MTW], const float (&bv)[NW]) {
+                    for (int n = 0; n < NW; ++n) bv[n] = Zs[(n * 16 + li) * ZP + 4 * st + lg];
+                };
+                // same order as the conv kernel: first MFMA, LDS reads of the next k-step, the rest
+                auto mm_first = [&](const float (&av)[MTW], const float (&bv)[NW]) {
+                    acc[0][0] = mfma16(av[0], bv[0], acc[0][0]);
+                };
+                auto mm_rest = [&](const float (&av)[MTW], const float (&bv)[NW]) {
 #pragma unroll
-                for (int mt = 0; mt < MTW; ++mt) {
-                    if (mt < nact) {
+                    for (int mt = 0; mt < MTW; ++mt) {
+                        if (FULL || mt < nact) {
 #pragma unroll
-                        for (int n = 0; n < NW; ++n)
-                            if (mt + n > 0) acc[mt][n] = mfma16(av[mt], bv[n], acc[mt][n]);
+                            for (int n = 0; n < NW; ++n)
+                                if (mt + n > 0) acc[mt][n] = mfma16(av[mt], bv[n], acc[mt][n]);
+                        }
                     }
+                };
+                auto pin = [&]() {
+                    if constexpr (FULL) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, MTW + NW, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, MTW * NW - 1, 0);
+                    }
+                };
+                const int npair = nsteps >> 1;
+                const int last = nsteps - 1;
+                ldop(0, a0, b0);
+                int st = 0;
+                for (int it = 0; it < npair; ++it, st += 2) {
+                    mm_first(a0, b0);
+                    ldop(st + 1, a1, b1);
+                    mm_rest(a0, b0);
+                    pin();
+                    mm_first(a1, b1);
+                    ldop(st + 2 < last ? st + 2 : last, a0, b0);
+                    mm_rest(a1, b1);
+                    pin();
+                }
+                if (nsteps & 1) {
+                    mm_first(a0, b0);
+                    mm_rest(a0, b0);
                 }
             };
-            auto pin = [&]() {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, MTW + NW, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, MTW * NW - 1, 0);
-            };
-            const int npair = nsteps >> 1;
-            const int last = nsteps - 1;
-            ldop(0, a0, b0);
-            int st = 0;
-            for (int it = 0; it < npair; ++it, st += 2) {
-                mm_first(a0, b0);
-                ldop(st + 1, a1, b1);
-                mm_rest(a0, b0);
-                pin();
-                mm_first(a1, b1);
-                ldop(st + 2 < last ? st + 2 : last, a0, b0);
-                mm_rest(a1, b1);
-                pin();
-            }
-            if (nsteps & 1) {
-                mm_first(a0, b0);
-                mm_rest(a0, b0);
-            }
+            run_unit(std::true_type{});      // dead tiles of a ragged last group read the ones row and are never stored
         }
     }
 
-    float* outp = a.out + (long long)split * a.split_stride;
     if (wb_noepi && acc[0][0][0] != 12345.678f) return;
+    if (!a.direct) {
+        // split partial, tile-major: each wave stores its accumulator tiles as contiguous 1 KiB
+        // runs (register order); wgrad_reduce_kernel sums the splits and does the scatter to the
+        // [K][Cin][Cout] layout once.  Dead tiles / padded columns are written too (finite) and
+        // ignored by the reduction.
+        f32x4* tile = reinterpret_cast<f32x4*>(a.out) +
+                      ((((long long)(a.split_base + split) * nMG + mg) * nNG + ng) * (MG * NG / 4)) +
+                      wave * (MTW * NW * 64) + lane;
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int n = 0; n < NW; ++n) tile[(mt * NW + n) * 64] = acc[mt][n];
+        return;
+    }
+    // single split: final layout directly (weights [K][Cin][Cout], then the bias row)
+    float* outp = a.out;
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
         if (mt >= nact) continue;
@@ -1102,6 +1239,61 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a, int nMG
                     outp[(long long)Mtot * a.N + col] = acc[mt][n][r4];
                 }
             }
+        }
+    }
+}
+
+// Sums the tile-major split partials of one weight gradient in split order (SL split lanes per
+// element, combined in lane order: deterministic) and scatters to the final layout:
+// out_w[K][Cin][Cout], out_b[Cout].  One thread = one f32x4 accumulator register of the tile.
+struct WgradReduceArgs {
+    const float* partial; float* out_w; float* out_b;
+    int nsplit, MTW, NW, nMG, nNG, Mtot, KW, Ctot, N;
+};
+
+template <int SL>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradReduceArgs a) {
+    __shared__ f32x4 red[SL > 1 ? 256 : 1];
+    constexpr int VPB = 256 / SL;                                  // vector slots per block
+    const int MG = 4 * a.MTW * 16, NG = a.NW * 16;
+    const int tile_v = MG * NG / 4;                                // f32x4 slots per tile
+    const int slot = threadIdx.x % VPB, sl = threadIdx.x / VPB;
+    const long long gv = (long long)blockIdx.x * VPB + slot;       // global slot over all tiles
+    const long long ntile = (long long)a.nMG * a.nNG;
+    const bool live = gv < ntile * tile_v;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(a.partial) + gv;
+        const long long sstride = ntile * tile_v;
+        for (int k = sl; k < a.nsplit; k += SL) sum += p[(long long)k * sstride];
+    }
+    if constexpr (SL > 1) {
+        red[threadIdx.x] = sum;
+        __syncthreads();
+        if (sl != 0) return;
+        sum = red[slot];
+#pragma unroll
+        for (int k = 1; k < SL; ++k) sum += red[k * VPB + slot];
+    }
+    if (!live) return;
+    const int t = (int)(gv / tile_v), v = (int)(gv % tile_v);
+    const int mg = t / a.nNG, ng = t % a.nNG;
+    const int per_wave = a.MTW * a.NW * 64;
+    const int wave = v / per_wave, rem = v % per_wave;
+    const int tn = rem / 64, lane = rem % 64;
+    const int mt = tn / a.NW, n = tn % a.NW;
+    const int li = lane & 15, lg = lane >> 4;
+    const int col = ng * NG + n * 16 + li;
+    if (col >= a.N) return;
+    const int r0 = mg * MG + (wave * a.MTW + mt) * 16 + lg * 4;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        const int r = r0 + r4;
+        if (r < a.Mtot) {
+            const int c = r / a.KW, kk = r - c * a.KW;
+            a.out_w[((long long)kk * a.Ctot + c) * a.N + col] = sum[r4];
+        } else if (r == a.Mtot) {
+            a.out_b[col] = sum[r4];
         }
     }
 }
@@ -1216,6 +1408,36 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
     WUN_WG(1, 5) WUN_WG(2, 5) WUN_WG(4, 5)
 #undef WUN_WG
     return hipErrorInvalidValue;
+}
+
+void wgrad_resolved_geom(const WgradArgs& a, int& mtw, int& nw) {
+    const WgradGeom g = wgrad_geom(a);
+    mtw = g.MTW; nw = g.NW;
+}
+
+// floats one split of this weight gradient occupies in the tile-major partial buffer
+long long wgrad_partial_floats(const WgradArgs& a) {
+    const WgradGeom g = wgrad_geom(a);
+    return (long long)g.nMG * g.nNG * (4 * g.MTW * 16) * (g.NW * 16);
+}
+
+// partial: `nsplit` consecutive splits written by launch_wgrad calls that share `a`'s tile geometry
+hipError_t launch_wgrad_reduce(const WgradArgs& a, const float* partial, int nsplit, float* out_w, float* out_b,
+                               hipStream_t s) {
+    const WgradGeom g = wgrad_geom(a);
+    WgradReduceArgs r;
+    r.partial = partial; r.out_w = out_w; r.out_b = out_b;
+    r.nsplit = nsplit; r.MTW = g.MTW; r.NW = g.NW; r.nMG = g.nMG; r.nNG = g.nNG;
+    r.Ctot = a.C0 + a.C1; r.KW = a.KW; r.Mtot = r.Ctot * a.KW; r.N = a.N;
+    const long long slots = (long long)g.nMG * g.nNG * (4 * g.MTW * 16) * (g.NW * 16) / 4;
+    // few elements but many splits: spread the splits over 4 / 16 lanes per element
+    const int sl = (nsplit >= 64 && slots < (1 << 16)) ? 16 : (nsplit >= 8 && slots < (1 << 18) ? 4 : 1);
+    const int vpb = 256 / sl;
+    const long long blocks = (slots + vpb - 1) / vpb;
+    if (sl == 16) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, r);
+    else if (sl == 4) hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, r);
+    else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, r);
+    return hipGetLastError();
 }
 
 // out[e] = sum_s partial[s*stride + e]  (fixed order -> deterministic)

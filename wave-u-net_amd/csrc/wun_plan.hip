@@ -313,7 +313,8 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
 
     // ---- wgrad partial buffer: max over layers of (total splits) * (kernel + bias floats) ----
     long long pmax = 0;
-    auto blockf = [](const ConvLayer& cl) { return (long long)cl.KW * cl.Cin * cl.Cout + cl.Cout; };
+    // floats per split in the tile-major partial buffer, worst-case tile padding (384 rows x 80 columns)
+    auto blockf = [](const ConvLayer& cl) { return ((long long)cl.KW * cl.Cin + 1 + 384) * (cl.Cout + 80); };
     for (int i = 0; i < L; ++i) {
         const DownShape& d = p->dsh[i];
         long long ns;
@@ -330,6 +331,7 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
         pmax = std::max(pmax, (long long)wgrad_pick_nsplit(wgrad_shape_only(B, p->ush[j].c_skip, p->ush[j].c_cur, Ku, LOADER_DIRECT, p->ush[j].cout, p->ush[j].t_conv)) * blockf(p->up[j]));
     if (p->Sh > 0)
         pmax = std::max(pmax, (long long)wgrad_pick_nsplit(wgrad_shape_only(B, C, F, Ko, LOADER_DIRECT, C, p->Tout)) * blockf(p->head[0]));
+    pmax *= 2;                                              // headroom for the autotuner's split counts
     p->partial_floats = pmax;
     p->partial_off = bump(w, pmax);
     p->ws = (w + 63) / 64 * 64;
@@ -615,6 +617,21 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
 // ---------------------------------------------------------------------------------------
 // loss + backward
 // ---------------------------------------------------------------------------------------
+// All parts of one layer's weight gradient (a down level has two: the decimated and the window
+// positions) use ONE tile geometry, so their splits land in one tile-major partial buffer that a
+// single reduction sums.  Returns false if the parts do not resolve to the same geometry.
+static bool wgrad_common_geom(WgradArgs* parts, int nparts, int mtw, int nw) {
+    int m0 = 0, n0 = 0;
+    for (int i = 0; i < nparts; ++i) {
+        parts[i].force_mtw = mtw; parts[i].force_nw = nw;
+        int m, n;
+        wgrad_resolved_geom(parts[i], m, n);
+        if (i == 0) { m0 = m; n0 = n; }
+        else if (m != m0 || n != n0) return false;
+    }
+    return true;
+}
+
 static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const ConvLayer& cl, float* ws,
                      float* grads, hipStream_t main, hipStream_t s) {
     // everything this weight gradient reads (dz, activations) has been issued on `main`
@@ -622,70 +639,84 @@ static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const Conv
         int rcd = stream_dep(p, main, s);
         if (rcd) return rcd;
     }
-    const long long blk = (long long)cl.KW * cl.Cin * cl.Cout + cl.Cout;
     float* partial = ws + p->partial_off;
-    int total = 0;
-    for (int i = 0; i < nparts; ++i) {
-        const size_t idx = p->wi++;
-        parts[i].nsplit = wgrad_pick_nsplit(parts[i]);
-        if (p->tune_mode == 1) {
-            if (p->wg_bwd.size() <= idx) p->wg_bwd.resize(idx + 1, WgradChoice{0, 0, 0});
-            // candidates: geometry x split count, each timed together with its split reduction
-            const long long cap_splits = p->partial_floats / blk / nparts;
-            auto run = [&](const WgradArgs& w) -> hipError_t {
-                WgradArgs q = w;
-                q.out = partial; q.split_stride = blk;
-                hipError_t e = launch_wgrad(q, s);
-                if (e != hipSuccess || q.nsplit == 1) return e;
-                return launch_reduce(partial, blk, q.nsplit, grads + cl.woff, blk, s);
-            };
-            float best = time_launch(p, s, [&]() { return run(parts[i]); });
-            const float base = best;
-            WgradChoice bc{0, 0, 0};
-            static const int mtws[] = {6, 4, 2, 1};
-            for (int mi = 0; mi < 4; ++mi)
-                for (int nw = 5; nw >= 1; --nw) {
-                    if (nw > 3 && (mtws[mi] == 6 || parts[i].N <= 48)) continue;
-                    WgradArgs g = parts[i];
-                    g.force_mtw = mtws[mi]; g.force_nw = nw;
-                    const int units = wgrad_max_units(g);
-                    const int base = wgrad_pick_nsplit(g);
-                    const int opts[4] = {base, base / 2, base * 2, base / 4};
-                    for (int oi = 0; oi < 4; ++oi) {
-                        int ns = opts[oi];
-                        if (ns < 1 || ns > units || ns > cap_splits) continue;
-                        if (oi > 0 && ns == opts[0]) continue;
-                        g.nsplit = ns;
-                        const float ms = time_launch(p, s, [&]() { return run(g); });
-                        if (ms < best * 0.98f) { best = ms; bc = WgradChoice{g.force_mtw, g.force_nw, ns}; }
+    float* out_w = grads + cl.woff;
+    float* out_b = out_w + (long long)cl.KW * cl.Cin * cl.Cout;
+    const size_t idx = p->wi++;
+    // default: the heuristic geometry of the largest part, lowered until every part agrees
+    {
+        int m, n;
+        parts[0].force_mtw = parts[0].force_nw = 0;
+        wgrad_resolved_geom(parts[0], m, n);
+        while (!wgrad_common_geom(parts, nparts, m, n) && m > 1) m = m == 6 ? 4 : m / 2;
+    }
+    for (int i = 0; i < nparts; ++i) parts[i].nsplit = wgrad_pick_nsplit(parts[i]);
+
+    auto run = [&](WgradArgs* q) -> hipError_t {
+        int total = 0;
+        for (int i = 0; i < nparts; ++i) total += q[i].nsplit;
+        if (total == 1) {
+            q[0].out = out_w; q[0].direct = 1; q[0].split_base = 0;
+            return launch_wgrad(q[0], s);
+        }
+        if (total * wgrad_partial_floats(q[0]) > p->partial_floats) return hipErrorOutOfMemory;
+        int done = 0;
+        for (int i = 0; i < nparts; ++i) {
+            q[i].out = partial; q[i].direct = 0; q[i].split_base = done;
+            hipError_t e = launch_wgrad(q[i], s);
+            if (e != hipSuccess) return e;
+            done += q[i].nsplit;
+        }
+        return launch_wgrad_reduce(q[0], partial, total, out_w, out_b, s);
+    };
+
+    if (p->tune_mode == 1) {
+        if (p->wg_bwd.size() <= idx) p->wg_bwd.resize(idx + 1, WgradChoice{0, 0, {0, 0}});
+        // candidates: shared geometry x per-part split counts, timed with the split reduction
+        float best = time_launch(p, s, [&]() { return run(parts); });
+        const float base = best;
+        WgradChoice bc{0, 0, {0, 0}};
+        static const int mtws[] = {6, 4, 2, 1};
+        WgradArgs g[2];
+        for (int mi = 0; mi < 4; ++mi)
+            for (int nw = 5; nw >= 1; --nw) {
+                if (nw > 3 && (mtws[mi] == 6 || parts[0].N <= 48)) continue;
+                for (int i = 0; i < nparts; ++i) g[i] = parts[i];
+                if (!wgrad_common_geom(g, nparts, mtws[mi], nw)) continue;
+                int m, n;
+                wgrad_resolved_geom(g[0], m, n);
+                if (m != mtws[mi] || n != nw) continue;          // lowered by the staging limit: duplicate
+                int basens[2] = {0, 0}, units[2] = {0, 0};
+                for (int i = 0; i < nparts; ++i) { basens[i] = wgrad_pick_nsplit(g[i]); units[i] = wgrad_max_units(g[i]); }
+                static const int num[4] = {4, 2, 8, 1};            // split factor / 4: 1, 1/2, 2, 1/4
+                for (int oi = 0; oi < 4; ++oi) {
+                    bool same = oi > 0;
+                    for (int i = 0; i < nparts; ++i) {
+                        int ns = basens[i] * num[oi] / 4;
+                        if (ns < 1) ns = 1;
+                        if (ns > units[i]) ns = units[i];
+                        if (ns != basens[i]) same = false;
+                        g[i].nsplit = ns;
                     }
+                    if (same) continue;
+                    const float ms = time_launch(p, s, [&]() { return run(g); });
+                    if (ms < best * 0.98f) { best = ms; bc = WgradChoice{mtws[mi], nw, {g[0].nsplit, nparts > 1 ? g[1].nsplit : 0}}; }
                 }
-            p->wg_bwd[idx] = bc;
-            if (getenv("WUN_TUNE_LOG"))
-                fprintf(stderr, "[tune wgrad #%zu] C=%d N=%d T=%d K=%d ld=%d base(ns=%d) %.3f ms -> mtw=%d nw=%d ns=%d %.3f ms\n",
-                        idx, parts[i].C0 + parts[i].C1, parts[i].N, parts[i].Tq, parts[i].KW, parts[i].loader,
-                        parts[i].nsplit, base, bc.mtw, bc.nw, bc.nsplit, best);
-        }
-        if (p->tune_mode >= 1 && idx < p->wg_bwd.size() && p->wg_bwd[idx].nsplit > 0) {
-            parts[i].force_mtw = p->wg_bwd[idx].mtw; parts[i].force_nw = p->wg_bwd[idx].nw;
-            parts[i].nsplit = p->wg_bwd[idx].nsplit;
-        }
-        total += parts[i].nsplit;
+            }
+        p->wg_bwd[idx] = bc;
+        if (getenv("WUN_TUNE_LOG"))
+            fprintf(stderr, "[tune wgrad #%zu] C=%d N=%d T=%d K=%d ld=%d parts=%d base(ns=%d) %.3f ms -> mtw=%d nw=%d ns=%d,%d %.3f ms\n",
+                    idx, parts[0].C0 + parts[0].C1, parts[0].N, parts[0].Tq, parts[0].KW, parts[0].loader, nparts,
+                    parts[0].nsplit, base, bc.mtw, bc.nw, bc.nsplit[0], bc.nsplit[1], best);
     }
-    if ((long long)total * blk > p->partial_floats) return fail(WUN_ERR_INVALID, "internal: wgrad partial buffer too small");
-    if (total == 1) {
-        parts[0].out = grads + cl.woff; parts[0].split_stride = blk;
-        HIP_TRY(launch_wgrad(parts[0], s));
-        return WUN_OK;
+    if (p->tune_mode >= 1 && idx < p->wg_bwd.size() && p->wg_bwd[idx].nsplit[0] > 0) {
+        const WgradChoice& c = p->wg_bwd[idx];
+        if (wgrad_common_geom(parts, nparts, c.mtw, c.nw))
+            for (int i = 0; i < nparts; ++i) parts[i].nsplit = c.nsplit[i];
     }
-    int done = 0;
-    for (int i = 0; i < nparts; ++i) {
-        parts[i].out = partial + (long long)done * blk;
-        parts[i].split_stride = blk;
-        HIP_TRY(launch_wgrad(parts[i], s));
-        done += parts[i].nsplit;
-    }
-    HIP_TRY(launch_reduce(partial, blk, total, grads + cl.woff, blk, s));
+    hipError_t e = run(parts);
+    if (e == hipErrorOutOfMemory) return fail(WUN_ERR_INVALID, "internal: wgrad partial buffer too small");
+    HIP_TRY(e);
     return WUN_OK;
 }
 
@@ -911,6 +942,7 @@ extern "C" int wun_adam_step(const wun_plan* p, float* params, const float* grad
 // ---------------------------------------------------------------------------------------
 // the single-operator entry points use a lazily allocated split-K scratch of their own
 static const long long kOpScratchFloats = 8ll << 20;
+static int g_op_variant = -1, g_op_ksplit = 0;          // wun_op_force_conv_variant (test hook)
 static float* op_scratch() {
     static float* buf = nullptr;
     if (!buf && hipMalloc((void**)&buf, kOpScratchFloats * sizeof(float)) != hipSuccess) {
@@ -918,6 +950,11 @@ static float* op_scratch() {
         (void)hipGetLastError();
     }
     return buf;
+}
+
+static hipError_t op_launch_conv(ConvArgs a, hipStream_t s) {
+    if (g_op_variant >= 0 && !(a.flags & F_PHASE2)) { a.force_variant = g_op_variant + 1; a.force_ksplit = g_op_ksplit; }
+    return launch_conv(a, op_scratch(), kOpScratchFloats, s);
 }
 
 static void op_src(ConvArgs& a, const float* x, int C, int T) {
@@ -938,7 +975,7 @@ extern "C" int wun_op_conv1d(const float* x, const float* w, const float* bias, 
     a.Tin = t_in; a.shift = pad_left; a.W = w; a.bias = bias; a.KW = k; a.N = a.N0 = cout; a.Tout = t_out;
     a.flags = lrelu ? F_LRELU : 0;
     a.dst0 = y; a.obs0 = (long long)cout * t_out; a.opitch0 = t_out;
-    HIP_TRY(launch_conv(a, op_scratch(), kOpScratchFloats, (hipStream_t)stream));
+    HIP_TRY(op_launch_conv(a, (hipStream_t)stream));
     return WUN_OK;
 }
 
@@ -959,10 +996,9 @@ extern "C" int64_t wun_op_conv1d_wgrad_scratch(int batch, int cin, int cout, int
     // split partials (worst case over both loaders) + repacked copies of x (t_in <= 2*t_out + k) and dz
     WgradArgs a = wgrad_shape_only(batch, cin, 0, k, LOADER_DIRECT, cout, t_out);
     WgradArgs b = wgrad_shape_only(batch, cin, 0, k, LOADER_DEINT, cout, t_out);
-    const long long ns = std::max(wgrad_pick_nsplit(a), wgrad_pick_nsplit(b));
+    const long long part = std::max(wgrad_pick_nsplit(a) * wgrad_partial_floats(a), wgrad_pick_nsplit(b) * wgrad_partial_floats(b));
     const long long tin_max = 2ll * t_out + k + 8;
-    return ns * ((long long)k * cin * cout + cout) + (long long)batch * cin * pad4((int)tin_max) +
-           (long long)batch * cout * pad4(t_out) + 256;
+    return part + (long long)batch * cin * pad4((int)tin_max) + (long long)batch * cout * pad4(t_out) + 512;
 }
 
 extern "C" int wun_op_conv1d_wgrad(const float* x, const float* dz, float* dw, float* db, float* scratch,
@@ -984,11 +1020,10 @@ extern "C" int wun_op_conv1d_wgrad(const float* x, const float* dz, float* dw, f
                              hipMemcpyDeviceToDevice, s));
     WgradArgs w = op_wgrad_args(xs, zs, batch, cin, cout, k, t_in, t_out, stride, pad_left, xp, zp);
     w.nsplit = wgrad_pick_nsplit(w);
-    const long long blk = (long long)k * cin * cout + cout;
-    w.out = part; w.split_stride = blk;
+    part = (float*)(((uintptr_t)part + 255) & ~(uintptr_t)255);
+    w.out = part; w.direct = 0; w.split_base = 0;      // always through the split reduction (dw and db are separate buffers)
     HIP_TRY(launch_wgrad(w, s));
-    HIP_TRY(launch_reduce(part, blk, w.nsplit, dw, (long long)k * cin * cout, s));
-    HIP_TRY(launch_reduce(part + (long long)k * cin * cout, blk, w.nsplit, db, cout, s));
+    HIP_TRY(launch_wgrad_reduce(w, part, w.nsplit, dw, db, s));
     return WUN_OK;
 }
 
@@ -1007,7 +1042,7 @@ extern "C" int wun_op_conv1d_dgrad(const float* dz, const float* w, float* dx, f
         op_src(a, dz, cout, t_out);
         a.Tin = t_out; a.shift = k - 1 - pad_left; a.W = wt_scratch; a.KW = k; a.N = a.N0 = cin; a.Tout = t_in;
         a.dst0 = dx; a.obs0 = (long long)cin * t_in; a.opitch0 = t_in;
-        HIP_TRY(launch_conv(a, op_scratch(), kOpScratchFloats, s));
+        HIP_TRY(op_launch_conv(a, s));
     } else {
         if (pad_left != 0) return fail(WUN_ERR_UNSUPPORTED, "stride-2 dgrad supports pad_left == 0 only");
         const int J0 = (k + 1) / 2;
@@ -1022,7 +1057,7 @@ extern "C" int wun_op_conv1d_dgrad(const float* dz, const float* w, float* dx, f
             WtDesc d; d.src_off = 0; d.dst_off = 0; d.J = J0; d.C = cin; d.N = cout; d.k_last = 2 * (J0 - 1);
             d.k_step = k; d.mode = 1;
             HIP_TRY(launch_make_wt_one(w, wt_scratch, d, s));
-            HIP_TRY(launch_conv(f, op_scratch(), kOpScratchFloats, s));
+            HIP_TRY(op_launch_conv(f, s));
             return WUN_OK;
         }
         for (int ph = 0; ph < 2; ++ph) {
@@ -1037,9 +1072,14 @@ extern "C" int wun_op_conv1d_dgrad(const float* dz, const float* w, float* dx, f
             op_src(a, dz, cout, t_out);
             a.Tin = t_out; a.KW = Jp; a.shift = Jp - 1; a.W = wt; a.N = a.N0 = cin; a.Tout = (t_in - ph + 1) / 2;
             a.dst0 = dx; a.obs0 = (long long)cin * t_in; a.opitch0 = t_in; a.ooff0 = ph;
-            HIP_TRY(launch_conv(a, op_scratch(), kOpScratchFloats, s));
+            HIP_TRY(op_launch_conv(a, s));
         }
     }
+    return WUN_OK;
+}
+
+extern "C" int wun_op_force_conv_variant(int variant, int ksplit) {
+    g_op_variant = variant; g_op_ksplit = ksplit;
     return WUN_OK;
 }
 
