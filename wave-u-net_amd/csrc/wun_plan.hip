@@ -122,7 +122,7 @@ struct wun_plan {
     mutable size_t ci = 0, wi = 0;
     mutable bool in_bwd = false;
     mutable hipEvent_t tev0 = nullptr, tev1 = nullptr;
-    mutable hipStream_t side = nullptr;
+    mutable hipStream_t side = nullptr, side2 = nullptr;
     mutable std::vector<hipEvent_t> events;
     mutable size_t ev_next = 0;
 };
@@ -331,7 +331,7 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
         pmax = std::max(pmax, (long long)wgrad_pick_nsplit(wgrad_shape_only(B, p->ush[j].c_skip, p->ush[j].c_cur, Ku, LOADER_DIRECT, p->ush[j].cout, p->ush[j].t_conv)) * blockf(p->up[j]));
     if (p->Sh > 0)
         pmax = std::max(pmax, (long long)wgrad_pick_nsplit(wgrad_shape_only(B, C, F, Ko, LOADER_DIRECT, C, p->Tout)) * blockf(p->head[0]));
-    pmax *= 2;                                              // headroom for the autotuner's split counts
+    pmax *= 4;                                              // two streams' halves, each with 2x headroom for the autotuner's split counts
     p->partial_floats = pmax;
     p->partial_off = bump(w, pmax);
     p->ws = (w + 63) / 64 * 64;
@@ -374,6 +374,7 @@ extern "C" void wun_plan_destroy(wun_plan* p) {
     for (auto e : p->events) (void)hipEventDestroy(e);
     if (p->tev0) { (void)hipEventDestroy(p->tev0); (void)hipEventDestroy(p->tev1); }
     if (p->side) (void)hipStreamDestroy(p->side);
+    if (p->side2) (void)hipStreamDestroy(p->side2);
     delete p;
 }
 
@@ -463,7 +464,8 @@ static int side_init(const wun_plan* p) {
     if (p->side != nullptr) return WUN_OK;
     if (getenv("WUN_SINGLE_STREAM") != nullptr) return WUN_OK;      // debugging: everything on one stream
     HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
-    p->events.resize(96);
+    if (getenv("WUN_TWO_STREAMS") == nullptr) HIP_TRY(hipStreamCreateWithFlags(&p->side2, hipStreamNonBlocking));
+    p->events.resize(160);
     for (auto& e : p->events) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return WUN_OK;
 }
@@ -639,7 +641,9 @@ static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const Conv
         int rcd = stream_dep(p, main, s);
         if (rcd) return rcd;
     }
-    float* partial = ws + p->partial_off;
+    // weight gradients alternate between two side streams; each has its own half of the partial buffer
+    const long long pcap = p->partial_floats / 2;
+    float* partial = ws + p->partial_off + ((p->side2 && s == p->side2) ? pcap : 0);
     float* out_w = grads + cl.woff;
     float* out_b = out_w + (long long)cl.KW * cl.Cin * cl.Cout;
     const size_t idx = p->wi++;
@@ -659,7 +663,7 @@ static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const Conv
             q[0].out = out_w; q[0].direct = 1; q[0].split_base = 0;
             return launch_wgrad(q[0], s);
         }
-        if (total * wgrad_partial_floats(q[0]) > p->partial_floats) return hipErrorOutOfMemory;
+        if (total * wgrad_partial_floats(q[0]) > pcap) return hipErrorOutOfMemory;
         int done = 0;
         for (int i = 0; i < nparts; ++i) {
             q[i].out = partial; q[i].direct = 0; q[i].split_base = done;
@@ -758,7 +762,20 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
     int rc;
     if ((rc = side_init(p))) return rc;
     p->ci = 0; p->wi = 0; p->in_bwd = true;
-    hipStream_t s2 = (p->side && !g_profiling && p->tune_mode != 1) ? p->side : s;   // side stream: weight gradients + their reductions
+    // side streams: weight gradients + their reductions, alternating between two streams so the
+    // ramp-up / drain of consecutive (independent) weight-gradient kernels overlap
+    hipStream_t s2 = (p->side && !g_profiling && p->tune_mode != 1) ? p->side : s;
+    hipStream_t s3 = (p->side2 && s2 != s) ? p->side2 : s2;
+    int wg_rr = 0;
+    auto wstream = [&]() { return (wg_rr++ & 1) ? s3 : s2; };
+    // bucket events are recorded on s2 once it has also seen everything queued on s3
+    auto ready2 = [&](long long floor) -> int {
+        if (s3 != s2 && sig.next < sig.n && sig.starts[sig.next] >= floor) {
+            int rcj = stream_dep(p, s3, s2);
+            if (rcj) return rcj;
+        }
+        return sig.ready(floor, s2);
+    };
 
     HIP_TRY(launch_make_wt(params, ws, p->dev_wt, (int)p->wt.size(), p->wt_max, s));
 
@@ -776,9 +793,9 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
         wset_src1(w, ws, p->upo[L - 1], 0, F);
         w.Tin = p->t_feat; w.shift = h.padl; w.KW = Ko;
         wset_dz(w, h.dpre + (long long)sh * h.dps, h.dpbs, h.dppitch, C, p->Tout);
-        if ((rc = run_wgrad(p, &w, 1, p->head[sh], ws, grads, s, s2))) return rc;
+        if ((rc = run_wgrad(p, &w, 1, p->head[sh], ws, grads, s, wstream()))) return rc;
     }
-    if (p->Sh > 0 && (rc = sig.ready(p->head[0].woff, s2))) return rc;
+    if (p->Sh > 0 && (rc = ready2(p->head[0].woff))) return rc;
 
     // ---- up path, last level first ----
     for (int j = L - 1; j >= 0; --j) {
@@ -790,10 +807,10 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
             wset_src1(w, ws, p->ups[j], 0, u.c_cur);
             w.Tin = u.t_up; w.shift = padU; w.KW = Ku;
             wset_dz(w, ws + p->dz_upo[j].off, p->dz_upo[j].bs, p->dz_upo[j].pitch, u.cout, u.t_conv);
-            if ((rc = run_wgrad(p, &w, 1, p->up[j], ws, grads, s, s2))) return rc;
+            if ((rc = run_wgrad(p, &w, 1, p->up[j], ws, grads, s, wstream()))) return rc;
             // (interp_j, written on `s` by the previous level's upsample_bwd, sits above up[j] in
             // the arena; run_wgrad made s2 wait for everything issued on `s` so far)
-            if ((rc = sig.ready(p->up[j].woff, s2))) return rc;
+            if ((rc = ready2(p->up[j].woff))) return rc;
         }
         {
             ConvArgs a = conv_base(p);
@@ -825,8 +842,8 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
         wset_src0(w, ws, p->dec[L - 1], 0, p->bott.Cin);
         w.Tin = p->t_b_in; w.shift = padD; w.KW = Kd;
         wset_dz(w, ws + p->dz_bott.off, p->dz_bott.bs, p->dz_bott.pitch, p->c_b, p->t_b);
-        if ((rc = run_wgrad(p, &w, 1, p->bott, ws, grads, s, s2))) return rc;
-        if ((rc = sig.ready(p->bott.woff, s2))) return rc;
+        if ((rc = run_wgrad(p, &w, 1, p->bott, ws, grads, s, wstream()))) return rc;
+        if ((rc = ready2(p->bott.woff))) return rc;
         ConvArgs a = conv_base(p);
         set_src0(a, ws, p->dz_bott, 0, p->c_b);
         a.Tin = p->t_b; a.shift = Kd - 1 - padD; a.W = ws + p->bott.wt_full; a.KW = Kd;
@@ -850,8 +867,8 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
             wset_src0(w, ws, x, 0, d.cin);
             w.Tin = d.t_in; w.shift = padD; w.KW = Kd;
             wset_dz(w, ws + p->dz_skip[i].off, p->dz_skip[i].bs, p->dz_skip[i].pitch, d.cout, d.t_conv);
-            if ((rc = run_wgrad(p, &w, 1, cl, ws, grads, s, s2))) return rc;
-            if ((rc = sig.ready(cl.woff, s2))) return rc;
+            if ((rc = run_wgrad(p, &w, 1, cl, ws, grads, s, wstream()))) return rc;
+            if ((rc = ready2(cl.woff))) return rc;
             if (i > 0) {
                 ConvArgs a = conv_base(p);
                 set_src0(a, ws, p->dz_skip[i], 0, d.cout);
@@ -871,8 +888,8 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
             wset_src0(w[1], ws, x, d.cs, d.cin);
             w[1].Tin = d.tc + Kd - 1; w[1].shift = 0; w[1].KW = Kd;
             wset_dz(w[1], ws + p->dz_skip[i].off, p->dz_skip[i].bs, p->dz_skip[i].pitch, d.cout, d.tc);
-            if ((rc = run_wgrad(p, w, 2, cl, ws, grads, s, s2))) return rc;
-            if ((rc = sig.ready(cl.woff, s2))) return rc;
+            if ((rc = run_wgrad(p, w, 2, cl, ws, grads, s, wstream()))) return rc;
+            if ((rc = ready2(cl.woff))) return rc;
             if (i > 0) {
                 // transposed stride-2 conv: both output phases fused in one launch (a lane owns 8
                 // consecutive outputs) when the launch fills the chip, else one phase at a time
@@ -905,6 +922,7 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
             }
         }
     }
+    if ((rc = stream_dep(p, s3, s))) return rc;
     if ((rc = stream_dep(p, s2, s))) return rc;      // all gradients are complete w.r.t. `stream`
     if ((rc = sig.ready(0, s))) return rc;           // any bucket not yet signalled (e.g. single-stream mode)
     return WUN_OK;
