@@ -57,3 +57,31 @@ def predict_track(model_config, separator, mix_audio, mix_sr=None, batch_hops=16
     if extra_pad > 0:                                                            # :141-143
         preds = {n: v[:-extra_pad, :] for n, v in preds.items()}
     return preds
+
+
+def produce_source_estimates(model_config, load_model, input_path, output_path=None, separator=None):
+    """Evaluate.produce_source_estimates (Evaluate.py:160-194): separate one mixture file with a
+    checkpoint and write <input file name>_<source>.wav next to it (or into output_path).  WAV/NPY
+    input at expected_sr (no resampling, no MP3 decoding here).  Returns {source: [T, C]}."""
+    import os
+    from scipy.io import wavfile
+    from . import datasets
+    from .separator import UnetAudioSeparator
+    audio = datasets.load_audio(input_path, mono=False, expected_sr=model_config["expected_sr"])
+    sep = separator if separator is not None else UnetAudioSeparator(model_config)
+    if load_model is not None:
+        state = np.load(load_model)
+        sep.load_variables({k: state[k] for k in state.files if k.startswith("separator/")})
+    preds = predict_track(model_config, sep, audio, model_config["expected_sr"])
+    # Evaluate.predict (:59-80): mono models are evaluated on the downmix; estimates are tiled back to
+    # the input's channel count
+    if model_config["mono_downmix"] and audio.shape[1] > 1:
+        preds = {k: np.tile(v, [1, audio.shape[1]]) for k, v in preds.items()}
+    folder, name = os.path.split(input_path)
+    if output_path is None:
+        output_path = folder
+    os.makedirs(output_path or ".", exist_ok=True)
+    for source_name, source_audio in preds.items():
+        wavfile.write(os.path.join(output_path, name) + "_" + source_name + ".wav", int(model_config["expected_sr"]),
+                      np.asarray(source_audio, np.float32))
+    return preds

@@ -143,22 +143,32 @@ class UnetAudioSeparator(object):
         self.adam_m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.adam_v = torch.zeros(n, dtype=torch.float32, device=dev)
 
+    def _any_plan(self):
+        """The variable table is the same for every (batch, frames): use any plan, creating a
+        minimal one if the separator has not been run yet."""
+        if self._active is not None:
+            return self._active
+        if not self._plans:
+            self.variable_table()
+        return next(iter(self._plans.values()))
+
     def variables(self):
         """dict tf_name -> tensor view into the flat arena."""
-        plan = self._active or next(iter(self._plans.values()))
+        plan = self._any_plan()
+        self._ensure_variables(plan)
         return {name: self.params[off:off + int(np.prod(shp))].view(*shp)
                 for name, off, shp in plan.tensors}
 
     def gradients(self):
-        plan = self._active or next(iter(self._plans.values()))
+        plan = self._any_plan()
+        self._ensure_variables(plan)
         return {name: self.grads[off:off + int(np.prod(shp))].view(*shp)
                 for name, off, shp in plan.tensors}
 
     def load_variables(self, named):
-        """named: dict or list of (tf_name, array).  Requires a plan (call get_output or
-        variable_table first)."""
+        """named: dict or list of (tf_name, array)."""
         items = named.items() if isinstance(named, dict) else named
-        plan = self._active or next(iter(self._plans.values()))
+        plan = self._any_plan()
         self._ensure_variables(plan)
         index = {name: (off, shp) for name, off, shp in plan.tensors}
         for name, val in items:

@@ -2,10 +2,11 @@
 (/root/reference/Training.py:24-121): build the separator once, run `epoch_it` steps of
 {forward, MSE loss, backward, Adam}, count global_step, return a checkpoint path.
 
-The reference feeds the step from a tf.data pipeline over MUSDB (Datasets.py) -- out of
-scope here; `batch_source` is any callable returning (mix [B,Tin,C], targets [S,B,Tout,C])
-GPU tensors honouring that pipeline's output contract (float32, mix = sum of sources,
-targets centre-cropped).  `synthetic_source` is the benchmark's generator.
+The reference feeds the step from a tf.data pipeline over MUSDB (Datasets.py); here
+`batch_source` is any callable returning (mix [B,Tin,C], targets [S,B,Tout,C]) GPU tensors
+honouring that pipeline's output contract (float32, mix = sum of sources, targets
+centre-cropped): datasets.DeviceSnippetSource for real tracks, `synthetic_source` for the
+benchmark.
 """
 import json
 import os
@@ -103,6 +104,8 @@ def train(model_config, experiment_id, load_model=None, batch_source=None, log_e
     if batch_source is None:
         batch_source = synthetic_source(model_config, tr.batch, tr.t_in, tr.t_out, tr.device,
                                         seed=1337 + tr.rank)
+    elif getattr(batch_source, "needs_trainer", False):
+        batch_source = batch_source(tr)          # factory: needs the trainer's device / shapes / rank
     log_dir = os.path.join(model_config["log_dir"], str(experiment_id))
     if tr.rank == 0:
         os.makedirs(log_dir, exist_ok=True)

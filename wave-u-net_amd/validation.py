@@ -1,0 +1,103 @@
+"""Validation loss and the early-stopping driver around the training path: the reference's
+Test.test (/root/reference/Test.py:11-92) and Training.optimise (/root/reference/Training.py:123-151).
+
+test() = mean over the partition's batches of  (1/S) sum_src mean((real - est)^2)  with the
+separator run in inference mode (training=False, so the "linear" head clips, Test.py:34), as a running
+mean over batches (Test.py:77-84).  optimise() = epochs of train() until the validation loss has
+not improved for `worse_epochs` epochs, then a fine-tuning round with batch_size doubled and
+init_sup_sep_lr = 1e-5, then the test-partition loss of the best checkpoint.
+"""
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import datasets
+from .separator import UnetAudioSeparator
+from .training import train
+
+
+def _load_checkpoint(separator, load_model):
+    state = np.load(load_model)
+    separator.load_variables({k: state[k] for k in state.files if k.startswith("separator/")})
+    return int(state["global_step"]) if "global_step" in state.files else 0
+
+
+def test(model_config, partition, model_folder, load_model, tracks=None, data_root=None, separator=None):
+    """Test.test(model_config, partition, model_folder, load_model) -> mean MSE.  The partition's
+    tracks come from `tracks` (list of track dicts) or data_root/<partition>/<track>/."""
+    if model_config["network"] != "unet":
+        raise NotImplementedError(model_config["network"])                        # Test.py:14-19
+    if tracks is None:
+        if data_root is None:
+            raise ValueError("test() needs `tracks` or `data_root`")
+        tracks = datasets.load_partition(data_root, partition, model_config)
+    sep = separator if separator is not None else UnetAudioSeparator(model_config)
+    disc_input_shape = [model_config["batch_size"], model_config["num_frames"], 0]
+    in_shape, out_shape = sep.get_padding(np.array(disc_input_shape))            # Test.py:21
+    assert (in_shape[1] - out_shape[1]) % 2 == 0                                  # Test.py:25
+    global_step = _load_checkpoint(sep, load_model) if load_model is not None else 0
+
+    total_loss, batch_num = 0.0, 1
+    names = list(model_config["source_names"])
+    for batch in datasets.get_dataset(model_config, in_shape, out_shape, partition, tracks):
+        outs = sep.get_output(batch["mix"], False)                                # Test.py:34
+        loss = 0.0
+        for key in names:                                                         # Test.py:61-74
+            real = torch.as_tensor(batch[key], device=outs[key].device)
+            loss = loss + torch.mean((real - outs[key]) ** 2)
+        curr = float(loss.item()) / float(model_config["num_sources"])
+        total_loss = total_loss + (1.0 / float(batch_num)) * (curr - total_loss)  # Test.py:80
+        batch_num += 1
+
+    log_dir = os.path.join(model_config["log_dir"], str(model_folder))            # Test.py:41,86-87
+    os.makedirs(log_dir, exist_ok=True)
+    with open(os.path.join(log_dir, "test.jsonl"), "a") as f:
+        f.write(json.dumps({"global_step": global_step, "partition": partition, "test_loss": total_loss}) + "\n")
+    return total_loss
+
+
+def optimise(model_config, experiment_id, data=None, data_root=None, max_epochs=None):
+    """Training.optimise -> (best_model_path, test_loss).  `data` = {"train": [...], "valid": [...],
+    "test": [...]} track lists (or data_root with those sub-directories).  max_epochs bounds the
+    total number of epochs (the reference has no bound; tests need one)."""
+    if data is None:
+        if data_root is None:
+            raise ValueError("optimise() needs `data` or `data_root`")
+        data = {part: datasets.load_partition(data_root, part, model_config) for part in ("train", "valid", "test")}
+    model_config = dict(model_config)
+    epoch = 0
+    best_loss = 10000
+    model_path = None
+    best_model_path = None
+    for i in range(2):
+        worse_epochs = 0
+        if i == 1:                                                                # Training.py:131-134
+            model_config["batch_size"] *= 2
+            model_config["init_sup_sep_lr"] = 1e-5
+        while worse_epochs < model_config["worse_epochs"]:                        # Training.py:135
+            if max_epochs is not None and epoch >= max_epochs:
+                break
+            model_path = train(model_config, experiment_id, load_model=model_path,
+                               batch_source=_train_source(model_config, data["train"], seed=1337 + epoch))
+            curr_loss = test(model_config, "valid", str(experiment_id), model_path, tracks=data["valid"])
+            epoch += 1
+            if curr_loss < best_loss:
+                worse_epochs = 0
+                best_model_path = model_path
+                best_loss = curr_loss
+            else:
+                worse_epochs += 1
+    test_loss = test(model_config, "test", str(experiment_id), best_model_path, tracks=data["test"])
+    return best_model_path, test_loss
+
+
+def _train_source(model_config, tracks, seed):
+    """Deferred constructor: train() builds the Trainer first (it fixes device and shapes), then
+    asks for the batch source."""
+    def make(trainer):
+        return datasets.DeviceSnippetSource(model_config, tracks, trainer.t_in, trainer.t_out, trainer.batch,
+                                            trainer.device, seed=seed + trainer.rank)
+    make.needs_trainer = True
+    return make
