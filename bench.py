@@ -64,7 +64,9 @@ def pmc_traffic(kernel_name):
         table = json.load(open(path))["kernels"]
     except Exception:
         return None
-    key = kernel_name.replace(", true>", ">").replace(", false>", ">")
+    import re
+    m = re.match(r"conv_mfma_kernel<(\d+, \d+, \d+, \d+, \d+), (?:true|false)(?:, (true|false|fold))?>", kernel_name)
+    key = ("conv_mfma_kernel<%s%s>" % (m.group(1), ", fold" if m.group(2) in ("true", "fold") else "")) if m else kernel_name
     ent = table.get(key)
     return ent["hbm_bytes_per_launch"] if ent else None
 

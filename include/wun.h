@@ -126,6 +126,13 @@ int wun_loss_backward_ex(const wun_plan* plan, const float* params, const float*
 int wun_plan_tune(const wun_plan* plan, const float* params, const float* mix_btc, float* workspace,
                   float* outputs, const float* targets, float* grads, float* loss, void* stream);
 
+/* Tuned choices as text (one line per launch position), so a later process can reuse them without
+ * re-tuning: export writes a NUL-terminated string into buf (WUN_ERR_INVALID if cap is too small or
+ * the plan is untuned); import accepts that string for a plan of the same config / batch / length
+ * (WUN_ERR_INVALID otherwise) and switches the plan to the tuned choices. */
+int wun_plan_tune_export(const wun_plan* plan, char* buf, int64_t cap);
+int wun_plan_tune_import(const wun_plan* plan, const char* text);
+
 /* tf.train.AdamOptimizer update (Training.py:77), TF rule:
  *   lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v; theta -= lr_t*m/(sqrt(v)+eps); g := grad_scale*grad
  * step is 1-based.  grad_scale = 1/world_size after a sum all-reduce. */

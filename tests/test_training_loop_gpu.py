@@ -54,3 +54,28 @@ def test_autotuned_runs_agree_to_rounding(tmp_path, monkeypatch):
     for k in a.files:
         if k.startswith("separator/"):
             assert np.abs(a[k] - b[k]).max() <= 2e-5, k
+
+
+def test_tuning_table_export_import_roundtrip(tmp_path, monkeypatch):
+    """wun_plan_tune_export / _import: a second trainer that imports the table runs the same tilings
+    (bit-identical steps) without tuning; a table from another shape is rejected."""
+    monkeypatch.delenv("WUN_NO_TUNE", raising=False)
+    cache = os.path.join(str(tmp_path), "tune.txt")
+    monkeypatch.setenv("WUN_TUNE_CACHE", cache)
+    cfg = _cfg(str(tmp_path), 1)
+    ta = training.Trainer(cfg)
+    src = training.synthetic_source(cfg, ta.batch, ta.t_in, ta.t_out, ta.device)
+    mix, targets = src()
+    ta.tune(mix, targets)                                   # tunes and writes the table
+    text = open(cache).read()
+    assert text.startswith("wun-tune 1 B=4 ") and "\ncf " in text and "\nwg " in text
+    tb = training.Trainer(cfg)
+    tb.tune(mix, targets)                                   # imports: no tuning pass
+    assert tb.sep.tune_export() == text
+    la = [float(ta.step(mix, targets).item()) for _ in range(3)]
+    lb = [float(tb.step(mix, targets).item()) for _ in range(3)]
+    assert la == lb
+    assert torch.equal(ta.sep.params, tb.sep.params)
+    other = training.Trainer(dict(cfg, num_frames=72))
+    with pytest.raises(ValueError):
+        other.sep.tune_import(text)

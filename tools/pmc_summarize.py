@@ -9,6 +9,16 @@ import re
 import sys
 
 
+def canon(name):
+    """conv_mfma_kernel<4, 3, 4, 1, 8, true, false>(...) -> conv_mfma_kernel<4, 3, 4, 1, 8>; batch-folded
+    instantiations get a ', fold' marker.  Same rule as bench.py's pmc_traffic()."""
+    nm = re.sub(r"\(.*", "", name.replace("void wun::", "").replace("wun::", ""))
+    m = re.match(r"conv_mfma_kernel<(\d+, \d+, \d+, \d+, \d+), (?:true|false)(?:, (true|false|fold))?>", nm)
+    if m:
+        return "conv_mfma_kernel<%s%s>" % (m.group(1), ", fold" if m.group(2) in ("true", "fold") else "")
+    return nm
+
+
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     first = max(int(r["Dispatch_Id"]) for r in rows if "btc_to_ncw" in r["Kernel_Name"])
@@ -20,8 +30,7 @@ def main():
         d = int(r["Dispatch_Id"])
         if d < first:
             continue
-        nm = re.sub(r"\(.*", "", r["Kernel_Name"].replace("void wun::", "").replace("wun::", ""))
-        nm = nm.replace(", true>", ">").replace(", false>", ">")
+        nm = canon(r["Kernel_Name"])
         agg[nm][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[nm].add(d)
         if d not in seen:

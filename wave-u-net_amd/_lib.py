@@ -39,6 +39,8 @@ _SIGS = {
     "wun_loss_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "wun_loss_backward_ex": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.c_int32]),
     "wun_plan_tune": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "wun_plan_tune_export": (C.c_int, [_P, C.c_char_p, C.c_int64]),
+    "wun_plan_tune_import": (C.c_int, [_P, C.c_char_p]),
     "wun_adam_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float,
                                 C.c_float, C.c_float, _P]),
     "wun_op_conv1d": (C.c_int, [_P, _P, _P, _P] + [C.c_int] * 9 + [_P]),

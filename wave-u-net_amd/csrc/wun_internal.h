@@ -131,8 +131,6 @@ void wgrad_resolved_geom(const WgradArgs& a, int& mtw, int& nw);
 long long wgrad_partial_floats(const WgradArgs& a);
 hipError_t launch_wgrad_reduce(const WgradArgs& a, const float* partial, int nsplit, float* out_w, float* out_b,
                                hipStream_t s);
-hipError_t launch_reduce(const float* partial, long long stride, int nsplit, float* out,
-                         long long n, hipStream_t s);
 hipError_t launch_upsample(const UpsampleArgs& a, hipStream_t s);
 hipError_t launch_upsample_bwd(const UpsampleBwdArgs& a, hipStream_t s);
 hipError_t launch_head_fwd_off(const HeadArgs& a, const long long* hoff, hipStream_t s);

@@ -960,7 +960,7 @@ hipError_t launch_conv(const ConvArgs& a_in, float* part, long long part_cap, hi
 // =====================================================================================
 // D[(cin,tap) 16][cout 16] += A[(cin,tap)][q] * B[q][cout]; reduction over (batch, q) split
 // over workgroups ("units" of TK <= 128 output positions), partial sums to scratch, summed
-// in a fixed order by reduce_splits_*.  Row (cin,tap) of A is the input row `cin` read at
+// in a fixed order by wgrad_reduce_kernel.  Row (cin,tap) of A is the input row `cin` read at
 // offset `tap`, so one staged input row serves all taps.  Staging is 16-byte global loads
 // into registers one unit ahead of the MFMAs (aligned vectors; the sub-vector shift
 // `delta` is folded into the LDS read offset), de-interleaved into even/odd planes for the
@@ -1437,53 +1437,6 @@ hipError_t launch_wgrad_reduce(const WgradArgs& a, const float* partial, int nsp
     if (sl == 16) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, r);
     else if (sl == 4) hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, r);
     else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, r);
-    return hipGetLastError();
-}
-
-// out[e] = sum_s partial[s*stride + e]  (fixed order -> deterministic)
-__global__ void reduce_splits_kernel(const float* __restrict__ partial, long long stride, int nsplit,
-                                     float* __restrict__ out, long long n) {
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n;
-         e += (long long)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += partial[(long long)k * stride + e];
-        out[e] = s;
-    }
-}
-
-// many splits, few elements: 16 element lanes x 16 split lanes per block, fixed summation order
-__global__ __launch_bounds__(256) void reduce_splits_wide_kernel(const float* __restrict__ partial,
-                                                                 long long stride, int nsplit,
-                                                                 float* __restrict__ out, long long n) {
-    __shared__ float red[16][17];
-    const int ex = threadIdx.x & 15, y = threadIdx.x >> 4;
-    const long long e = (long long)blockIdx.x * 16 + ex;
-    float s = 0.f;
-    if (e < n)
-        for (int k = y; k < nsplit; k += 16) s += partial[(long long)k * stride + e];
-    red[y][ex] = s;
-    __syncthreads();
-    if (y == 0 && e < n) {
-        float t = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) t += red[k][ex];
-        out[e] = t;
-    }
-}
-
-hipError_t launch_reduce(const float* partial, long long stride, int nsplit, float* out,
-                         long long n, hipStream_t s) {
-    if (nsplit >= 8) {
-        const long long blocks = (n + 15) / 16;
-        hipLaunchKernelGGL(reduce_splits_wide_kernel, dim3((unsigned)blocks), dim3(256), 0, s, partial,
-                           stride, nsplit, out, n);
-        return hipGetLastError();
-    }
-    long long blocks = (n + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)blocks), dim3(256), 0, s, partial, stride,
-                       nsplit, out, n);
     return hipGetLastError();
 }
 

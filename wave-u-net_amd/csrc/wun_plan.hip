@@ -944,6 +944,54 @@ extern "C" int wun_plan_tune(const wun_plan* p, const float* params, const float
     return rc;
 }
 
+extern "C" int wun_plan_tune_export(const wun_plan* p, char* buf, int64_t cap) {
+    if (!p || !buf) return fail(WUN_ERR_INVALID, "null argument");
+    if (p->tune_mode != 2) return fail(WUN_ERR_INVALID, "plan has not been tuned");
+    std::string out;
+    char line[128];
+    snprintf(line, sizeof(line), "wun-tune 1 B=%d Tin=%lld L=%d F=%d arena=%lld\n", p->B, (long long)p->Tin, p->L,
+             p->cfg.num_initial_filters, (long long)p->arena);
+    out += line;
+    auto dump = [&](const char* tag, const std::vector<ConvChoice>& v) {
+        for (const ConvChoice& c : v) { snprintf(line, sizeof(line), "%s %d %d\n", tag, c.variant, c.ksplit); out += line; }
+    };
+    dump("cf", p->conv_fwd);
+    dump("cb", p->conv_bwd);
+    for (const WgradChoice& c : p->wg_bwd) {
+        snprintf(line, sizeof(line), "wg %d %d %d %d\n", c.mtw, c.nw, c.nsplit[0], c.nsplit[1]);
+        out += line;
+    }
+    if ((int64_t)out.size() + 1 > cap) return fail(WUN_ERR_INVALID, "buffer too small for the tuning table");
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return WUN_OK;
+}
+
+extern "C" int wun_plan_tune_import(const wun_plan* p, const char* text) {
+    if (!p || !text) return fail(WUN_ERR_INVALID, "null argument");
+    char want[128];
+    snprintf(want, sizeof(want), "wun-tune 1 B=%d Tin=%lld L=%d F=%d arena=%lld", p->B, (long long)p->Tin, p->L,
+             p->cfg.num_initial_filters, (long long)p->arena);
+    const char* nl = strchr(text, '\n');
+    if (!nl || strncmp(text, want, strlen(want)) != 0 || (size_t)(nl - text) != strlen(want))
+        return fail(WUN_ERR_INVALID, "tuning table belongs to a different plan");
+    std::vector<ConvChoice> cf, cb;
+    std::vector<WgradChoice> wg;
+    const char* q = nl + 1;
+    while (*q) {
+        int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        if (sscanf(q, "cf %d %d", &a0, &a1) == 2 && q[1] == 'f') cf.push_back(ConvChoice{a0, a1});
+        else if (sscanf(q, "cb %d %d", &a0, &a1) == 2 && q[1] == 'b') cb.push_back(ConvChoice{a0, a1});
+        else if (sscanf(q, "wg %d %d %d %d", &a0, &a1, &a2, &a3) == 4) wg.push_back(WgradChoice{a0, a1, {a2, a3}});
+        else return fail(WUN_ERR_INVALID, "malformed tuning table");
+        const char* e = strchr(q, '\n');
+        if (!e) break;
+        q = e + 1;
+    }
+    p->conv_fwd = cf; p->conv_bwd = cb; p->wg_bwd = wg;
+    p->tune_mode = 2;
+    return WUN_OK;
+}
+
 extern "C" int wun_adam_step(const wun_plan* p, float* params, const float* grads, float* m, float* v,
                              int64_t step, float lr, float beta1, float beta2, float eps, float grad_scale,
                              void* stream) {

@@ -257,6 +257,16 @@ class UnetAudioSeparator(object):
             self._stream()))
         return loss
 
+    def tune_export(self):
+        """The tuned per-launch choices of the active plan as text (wun_plan_tune_export)."""
+        buf = C.create_string_buffer(1 << 16)
+        _lib.check(self._lib.wun_plan_tune_export(self._active.handle, buf, len(buf)))
+        return buf.value.decode()
+
+    def tune_import(self, text):
+        """Reuse choices exported by a plan of the same config / batch / length (ValueError otherwise)."""
+        _lib.check(self._lib.wun_plan_tune_import(self._active.handle, text.encode()))
+
     def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
         """tf.train.AdamOptimizer(learning_rate=lr) update (Training.py:77) + global_step += 1."""
         self.global_step += 1

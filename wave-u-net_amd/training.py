@@ -68,9 +68,22 @@ class Trainer(object):
         self.lr = model_config["init_sup_sep_lr"]
 
     def tune(self, mix, targets):
-        """One-off kernel autotuning on a real batch (skipped with WUN_NO_TUNE=1)."""
-        if os.environ.get("WUN_NO_TUNE") is None:
-            self.sep.tune(mix, targets)
+        """One-off kernel autotuning on a real batch (skipped with WUN_NO_TUNE=1).  With
+        WUN_TUNE_CACHE=<file> the choices are read from / written to that file, so later processes
+        (profilers, restarts) run the same tilings without re-tuning."""
+        if os.environ.get("WUN_NO_TUNE") is not None:
+            return
+        cache = os.environ.get("WUN_TUNE_CACHE")
+        if cache and os.path.exists(cache):
+            try:
+                self.sep.tune_import(open(cache).read())
+                return
+            except ValueError:
+                pass                                     # other shape / config: tune afresh
+        self.sep.tune(mix, targets)
+        if cache and self.rank == 0:
+            with open(cache, "w") as f:
+                f.write(self.sep.tune_export())
 
     def step(self, mix, targets):
         self.sep.get_output(mix, True)
