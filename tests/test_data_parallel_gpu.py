@@ -1,0 +1,59 @@
+"""Data-parallel training on the real kernels: two ranks (torch.distributed.run, one process per
+rank) == one process on the concatenated batch.  The test box has one GPU, so both ranks share it and
+the exchange runs over gloo (WUN_DIST_BACKEND=gloo; RCCL refuses duplicate devices) -- everything
+else (bucket events recorded by the backward pass, overlapped per-bucket all-reduce on the
+communication stream, 1/N folded into Adam, parameter broadcast) is the production path."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_two_ranks_equal_one_process_on_the_global_batch(tmp_path, overlap):
+    import dp_worker
+    from wave_u_net_amd import training
+    steps = 3
+    out = os.path.join(str(tmp_path), "dp.npz")
+    env = dict(os.environ, WUN_DIST_BACKEND="gloo", WUN_NO_TUNE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if not overlap:
+        env["WUN_NO_OVERLAP"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "dp_worker.py"), out, str(steps)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    dp = np.load(out)
+    assert int(dp["world"]) == 2 and int(dp["overlap"]) == int(overlap)
+
+    os.environ["WUN_NO_TUNE"] = "1"
+    try:
+        cfg = dict(dp_worker.make_cfg(), batch_size=6)
+        tr = training.Trainer(cfg)
+        mix, targets = dp_worker.global_batch(cfg, tr.t_in, tr.t_out, 6)
+        mix, targets = mix.to(tr.device), targets.to(tr.device)
+        losses = [float(tr.step(mix, targets).item()) for _ in range(steps)]
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("WUN_NO_TUNE", None)
+    ref = tr.sep.params.cpu().numpy()
+    # rank 0's loss is the mean over ITS half of the batch; parameters see the global gradient
+    assert np.abs(dp["params"] - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    assert np.all(np.isfinite(dp["losses"])) and dp["losses"][-1] < dp["losses"][0] and losses[-1] < losses[0]

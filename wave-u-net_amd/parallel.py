@@ -27,7 +27,9 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # WUN_DIST_BACKEND=gloo runs the multi-rank flow without RCCL (e.g. two ranks sharing the
+            # one GPU of a test box: RCCL refuses duplicate devices, gloo stages through the host)
+            backend = os.environ.get("WUN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

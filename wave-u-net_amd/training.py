@@ -48,7 +48,7 @@ class Trainer(object):
         self.cfg = model_config
         self.rank, self.local_rank, self.world = init_distributed()
         if device is None:
-            device = "cuda:%d" % self.local_rank
+            device = "cuda:%d" % (self.local_rank % max(1, torch.cuda.device_count()))
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         self.sep = UnetAudioSeparator(model_config, device=self.device, seed=seed)
