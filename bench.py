@@ -169,8 +169,14 @@ def main():
         "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE.json configs[1]: M1 (12 levels, 24 ch, 15/5 filters, mono) with context, "
-                               "fwd+bwd+Adam, batch %d/GPU, %d -> %d samples" % (tr.batch, tr.t_in, tr.t_out),
+        "config": {"workload": ("BASELINE.json configs[1]: M1 (12 levels, 24 ch, 15/5 filters, mono) with context, "
+                                "fwd+bwd+Adam, batch %d/GPU, %d -> %d samples" % (tr.batch, tr.t_in, tr.t_out))
+                               if args.config == "m1_context" else
+                               ("named config %s (%d levels, %d base channels, %s, %d sources, %s padding), fwd+bwd+Adam, "
+                                "batch %d/GPU, %d -> %d samples" % (
+                                    args.config, cfg["num_layers"], cfg["num_initial_filters"],
+                                    "mono" if cfg["mono_downmix"] else "stereo", cfg["num_sources"],
+                                    "valid (context)" if cfg["context"] else "same", tr.batch, tr.t_in, tr.t_out)),
                    "named_config": args.config, "global_batch": world * tr.batch,
                    "input_frames": tr.t_in, "output_frames": tr.t_out,
                    "input_samples_per_s": world * tr.batch * tr.t_in * args.steps / elapsed,

@@ -50,6 +50,10 @@ NAMED_CONFIGS = {                # Config.py:52-161 (the Wave-U-Net ones)
                             "num_frames": 768 * 127 + 1024, "duration": 13},
     # BASELINE.json configs[1]: the M1 architecture run with input context (~147k samples in)
     "m1_context": {"context": True},
+    # BASELINE.json configs[4]: 16 levels / 48 base channels, stereo, 4 sources, same padding,
+    # 589 824-sample excerpts (9 * 2^16; a 16-level context model would need >= 2.1 M input samples)
+    "deep_l16_f48": {"num_layers": 16, "num_initial_filters": 48, "mono_downmix": False,
+                     "task": "multi_instrument", "output_type": "difference", "num_frames": 589824},
 }
 
 
