@@ -117,6 +117,21 @@ std::string prof_end() {
 // Low-parallelism launches (deep levels: few time tiles) are split over channel chunks
 // (split-K): raw partial tiles go to a scratch buffer and conv_splitk_epilogue_kernel sums
 // them in a fixed order and applies the epilogue.
+// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Remap the hardware block
+// id so that every XCD works on a CONTIGUOUS range of logical tiles: the tiles that share an input
+// window (the N tiles of one time tile, neighbouring time tiles' halos; for the weight gradient all
+// (row group, column group) tiles of one split) then hit the same L2 instead of fetching the window
+// once per XCD.
+__device__ __forceinline__ int xcd_contiguous_block(int bid, int grid) {
+#ifdef WUN_NO_XCD_REMAP
+    return bid;
+#else
+    const int per = grid >> 3, rem = grid & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
+#endif
+}
+
 #define WUN_JMAX 15
 
 //
@@ -153,7 +168,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
     const int lane = tid & 63;
     const int li = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int bid = blockIdx.x;
+    int bid = xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x);
     const int nt = bid % nNT; bid /= nNT;
     const int tt = bid % nTT; bid /= nTT;
     const int b = FOLD ? (tt * TT) / a.Tout : bid % a.B;      // FOLD: first excerpt of the tile
@@ -984,7 +999,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a, int nMG
     const int lane = tid & 63;
     const int li = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int bid = blockIdx.x;
+    int bid = xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x);
     const int ng = bid % nNG; bid /= nNG;
     const int mg = bid % nMG;
     const int split = bid / nMG;
