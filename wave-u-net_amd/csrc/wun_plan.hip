@@ -504,8 +504,8 @@ static hipError_t conv_dispatch(const wun_plan* p, ConvArgs a, float* part, long
     const size_t idx = p->ci++;
     if (p->tune_mode == 1) {
         if (vec.size() <= idx) vec.resize(idx + 1, ConvChoice{-1, 0});
-        ConvChoice cands[160];
-        const int n = conv_list_candidates(a, part ? cap : 0, cands, 160);
+        ConvChoice cands[640];
+        const int n = conv_list_candidates(a, part ? cap : 0, cands, 640);
         // the heuristic choice is the baseline; a candidate has to beat it by > 2 %
         float best = time_launch(p, s, [&]() { return launch_conv(a, part, cap, s); });
         const float base = best;
