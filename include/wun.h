@@ -14,6 +14,13 @@
  * (as void*), re-entrant across plans, and returns 0 or a negative wun_status; the
  * message is available from wun_last_error() (thread-local).  Nothing aborts.
  *
+ * Threading: one host thread drives a plan at a time (the reference is a single-threaded
+ * sess.run loop); different plans may be driven from different threads.  A plan also owns
+ * its side HIP streams / events, its split-reduction bookkeeping and -- after wun_plan_tune --
+ * the tuned launch table, so the plan is immutable in its SHAPES, not in that scheduling
+ * state.  wun_profile_begin/end and the wun_op_* entry points (single-operator tests and
+ * benchmarks) use process-global state and are not meant for concurrent use.
+ *
  * Tensor layouts at the boundary are the reference's: audio is float32 [B, T, C]
  * (channel-last, exactly what get_output receives/returns); kernels are TF layout
  * [K, Cin, Cout]; variables sit in a flat float32 arena in TF creation order
