@@ -47,9 +47,10 @@ typedef enum wun_status {
 typedef struct wun_config {
     int32_t num_layers;
     int32_t num_initial_filters;
-    int32_t filter_size;
-    int32_t merge_filter_size;
-    int32_t input_filter_size;
+    int32_t filter_size;        /* 1..15 (the register-staged loaders hold at most 15 taps;       */
+    int32_t merge_filter_size;  /*  larger sizes return WUN_ERR_UNSUPPORTED at plan creation)     */
+    int32_t input_filter_size;  /* used by get_padding only (UnetAudioSeparator.py:73); the graph */
+                                /* convolves layer 0 with filter_size (UnetAudioSeparator.py:98)   */
     int32_t output_filter_size;
     int32_t upsampling;         /* 0 = "linear", 1 = "learned"                                */
     int32_t output_type;        /* 0 = "direct", 1 = "difference"                             */
@@ -136,7 +137,11 @@ int wun_plan_tune(const wun_plan* plan, const float* params, const float* mix_bt
 /* Tuned choices as text (one line per launch position), so a later process can reuse them without
  * re-tuning: export writes a NUL-terminated string into buf (WUN_ERR_INVALID if cap is too small or
  * the plan is untuned); import accepts that string for a plan of the same config / batch / length
- * (WUN_ERR_INVALID otherwise) and switches the plan to the tuned choices. */
+ * written by the same library build (WUN_ERR_INVALID otherwise: the header line carries the config,
+ * the launch-order version and the entry counts, and the table ends with an "end" line, so stale or
+ * truncated tables are refused) and switches the plan to the tuned choices.  An entry that is not a
+ * legal choice for the launch at its position is ignored at launch time (heuristic choice instead);
+ * a split factor can never exceed the split-K scratch. */
 int wun_plan_tune_export(const wun_plan* plan, char* buf, int64_t cap);
 int wun_plan_tune_import(const wun_plan* plan, const char* text);
 
@@ -169,10 +174,30 @@ int wun_op_conv1d_dgrad(const float* dz, const float* w, float* dx, float* wt_sc
                         int batch, int cin, int cout, int k, int t_in, int t_out,
                         int stride, int pad_left, void* stream);
 
+/* The plan's general conv launch as a single operator: the input is the virtual channel-concat of
+ * x0 [B][c0][t_in] and (optionally) x1 [B][c1][t_in] (Utils.crop_and_concat, Utils.py:11-24, without
+ * the copy); output element q of channel n is stored at y[b][n][ooff + q*ostride] (y is [B][cout][t_y]);
+ * mask (same geometry as y, or NULL) multiplies by the LeakyReLU derivative of the value stored
+ * there (1 if > 0 else 0.2); accumulate adds to what y already holds.  Semantics otherwise as
+ * wun_op_conv1d. */
+int wun_op_conv1d_ex(const float* x0, int c0, const float* x1, int c1, const float* w, const float* bias,
+                     float* y, const float* mask, int batch, int cout, int k, int t_in, int t_out,
+                     int t_y, int stride, int pad_left, int lrelu, int accumulate, int ostride, int ooff,
+                     void* stream);
+
 /* Test hook: force the tile variant (index into the kernel's variant table, -1 = automatic) and
- * split-K factor (0 = automatic) of every following wun_op_conv1d / _dgrad launch, so the parity
- * tests can reach every tiling.  An infeasible choice makes the launch fail with WUN_ERR_HIP. */
+ * split-K factor (0 = automatic) of every following wun_op_conv1d / _ex / _dgrad launch, so the parity
+ * tests can reach every tiling.  A choice the dispatcher would never make for that launch (tile
+ * mostly padding, split past the scratch buffer, loader not supported by the tile) makes the
+ * launch fail with WUN_ERR_HIP -- it is rejected, not miscomputed. */
 int wun_op_force_conv_variant(int variant, int ksplit);
+int wun_op_num_conv_variants(void);
+
+/* Test hook for wun_op_conv1d_wgrad: force the weight-gradient tile geometry (mtw in {1,2,4,6} row
+ * tiles per wave, nw in 1..5 column tiles; 0,0 = automatic) and the number of reduction splits
+ * (0 = automatic).  Call wun_op_conv1d_wgrad_scratch AFTER forcing: the scratch size depends on it.
+ * A geometry the kernel's staging cannot hold for the shape fails with WUN_ERR_UNSUPPORTED. */
+int wun_op_force_wgrad_variant(int mtw, int nw, int nsplit);
 
 /* Lane layout probe of v_mfma_f32_16x16x4_f32: d[16][16] = a[16][4] * b[4][16] (row-major). */
 int wun_op_mfma_probe(const float* a, const float* b, float* d, void* stream);

@@ -23,8 +23,34 @@ def global_batch(cfg, t_in, t_out, n):
     return src()
 
 
+def resume_main(out):
+    """Two epochs of training.train with a checkpoint hand-over in between (what validation.optimise
+    does): every rank must come out with the same parameters, Adam slots and global_step."""
+    cfg = dict(make_cfg(), epoch_it=2, model_base_dir=os.path.join(os.path.dirname(out), "ckpt"),
+               log_dir=os.path.join(os.path.dirname(out), "logs"))
+    path = training.train(cfg, "dp", None)
+    assert path is not None and path.endswith("dp-2.npz"), path           # broadcast to every rank
+    tr_holder = {}
+    orig = training.Trainer
+
+    class Spy(orig):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            tr_holder["tr"] = self
+    training.Trainer = Spy
+    path2 = training.train(cfg, "dp", load_model=path)
+    tr = tr_holder["tr"]
+    assert path2.endswith("dp-4.npz"), path2
+    np.savez("%s.rank%d.npz" % (out, tr.rank), params=tr.sep.params.cpu().numpy(), m=tr.sep.adam_m.cpu().numpy(),
+             v=tr.sep.adam_v.cpu().numpy(), step=tr.sep.global_step, table=np.array(getattr(tr, "tune_table", "") or ""))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
 def main():
     out = sys.argv[1]
+    if sys.argv[2] == "resume":
+        return resume_main(out)
     steps = int(sys.argv[2])
     cfg = make_cfg()
     tr = training.Trainer(cfg)

@@ -109,3 +109,32 @@ def test_single_process_is_a_noop():
     ref = g.clone()
     red.all_reduce(g)
     assert torch.equal(g, ref) and red.grad_scale == 1.0
+
+
+def _early_stop_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    init_distributed(backend="gloo")
+    from wave_u_net_amd import validation
+    calls = []
+
+    def fake_test(model_config, partition, model_folder, load_model, tracks=None, **kw):
+        calls.append(partition)
+        return 0.25 + rank                     # what a rank evaluating its own (different) model would see
+
+    validation.test = fake_test
+    loss = validation._rank0_test({}, "valid", "x", None, [])
+    with open(os.path.join(out_dir, "r%d.txt" % rank), "w") as f:
+        f.write("%r %d" % (loss, len(calls)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_validation_loss_is_rank0s_on_every_rank(tmp_path):
+    """optimise() must take identical early-stopping decisions on all ranks: the validation loss is
+    computed on rank 0 only and broadcast (ranks diverged and the all-reduce hung)."""
+    port = _free_port()
+    mp.spawn(_early_stop_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = open(os.path.join(str(tmp_path), "r0.txt")).read().split()
+    r1 = open(os.path.join(str(tmp_path), "r1.txt")).read().split()
+    assert r0 == ["0.25", "1"] and r1 == ["0.25", "0"]

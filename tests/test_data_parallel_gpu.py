@@ -57,3 +57,22 @@ def test_two_ranks_equal_one_process_on_the_global_batch(tmp_path, overlap):
     # rank 0's loss is the mean over ITS half of the batch; parameters see the global gradient
     assert np.abs(dp["params"] - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
     assert np.all(np.isfinite(dp["losses"])) and dp["losses"][-1] < dp["losses"][0] and losses[-1] < losses[0]
+
+
+def test_two_rank_resume_keeps_replicas_identical(tmp_path):
+    """train() -> checkpoint -> train(load_model=...) on two ranks (the flow of validation.optimise):
+    rank 0 loads, parameters / Adam slots / global_step are broadcast, the checkpoint path reaches every
+    rank, and rank 0's tuning table is the one every rank imports."""
+    out = os.path.join(str(tmp_path), "resume")
+    env = dict(os.environ, WUN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WUN_NO_TUNE", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "dp_worker.py"), out, "resume"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a, b = np.load(out + ".rank0.npz"), np.load(out + ".rank1.npz")
+    assert int(a["step"]) == 4 and int(b["step"]) == 4
+    for k in ("params", "m", "v"):
+        assert np.array_equal(a[k], b[k]), k                 # bit-identical replicas (same tilings on both ranks)
+    assert str(a["table"]) == str(b["table"]) and str(a["table"]).startswith("wun-tune 2 ")

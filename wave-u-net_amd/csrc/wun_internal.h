@@ -123,6 +123,8 @@ hipError_t launch_conv(const ConvArgs& a, float* part, long long part_cap, hipSt
 double conv_flops(const ConvArgs& a);        // useful FLOPs (2*MACs) of the launch
 long long conv_natural_wgs_phase2(const ConvArgs& a);
 int conv_list_candidates(const ConvArgs& a, long long part_cap, ConvChoice* out, int maxn);
+bool conv_choice_ok(const ConvArgs& a, long long part_cap, int variant, int ksplit);
+int conv_num_variants();
 int wgrad_max_units(const WgradArgs& a);
 
 int  wgrad_pick_nsplit(const WgradArgs& a);

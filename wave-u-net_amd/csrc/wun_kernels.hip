@@ -846,6 +846,8 @@ static hipError_t conv_launch_t(ConvArgs a, int variant, float* part, long long 
         const int nchunks = (a.C0 + a.C1 + CKC - 1) / CKC;
         int want = a.force_ksplit > nchunks ? nchunks : a.force_ksplit;
         if (part == nullptr) want = 1;
+        const long long per = (long long)a.B * a.N * ((a.Tout + 3) & ~3);
+        if (want > 1 && (long long)want * per > part_cap) return hipErrorInvalidValue;   // would overrun the scratch
         cps = (nchunks + want - 1) / want;
         ksplit = (nchunks + cps - 1) / cps;
     }
@@ -873,40 +875,51 @@ static hipError_t conv_launch_t(ConvArgs a, int variant, float* part, long long 
     return hipGetLastError();
 }
 
+// Is (tile variant, split-K factor) a choice the dispatcher may use for this launch?  The single
+// rule set behind the autotuner's candidate list, the test hook's forced choices and imported
+// tuning tables: a choice that fails here is never launched (a stale table cannot push a split
+// past the partial scratch or select a tile the loader does not support).
+bool conv_choice_ok(const ConvArgs& a, long long part_cap, int v, int ks) {
+    const int nvar = (int)(sizeof(kConvVariants) / sizeof(kConvVariants[0]));
+    if (v < 0 || v >= nvar || ks < 1) return false;
+    const int Ctot = a.C0 + a.C1;
+    const bool phase2 = (a.flags & F_PHASE2) != 0;
+    if ((a.N & 3) != 0) return false;                                // scalar-weight fallback: fixed menu
+    const ConvVariant& cv = kConvVariants[v];
+    if (Ctot <= 4 && cv.CK != 4) return false;
+    if (Ctot > 4 && cv.CK == 4 && (a.loader == LOADER_DEINT || phase2 || v < 26)) return false;
+    if (phase2 && !(cv.WN == 1 && (cv.NW % 2) == 0)) return false;
+    if (cv.fold && !conv_fold_ok(a, v)) return false;
+    const int TT = cv.WT * cv.MT * 16;
+    const int NT = phase2 ? cv.WN * cv.NW * 8 : cv.WN * cv.NW * 16;   // channels per workgroup
+    if (!cv.fold && TT > 16 && TT >= 2 * a.Tout) return false;       // mostly padding in time
+    if (cv.fold && (long long)TT >= 2ll * a.B * a.Tout) return false;
+    const int padded = ((a.N + NT - 1) / NT) * NT;
+    if (padded * 3 > a.N * 4 + 48) return false;                      // > ~33 % padded columns
+    if (conv_lds_bytes(a, v) > 150 * 1024) return false;
+    if (ks == 1) return true;
+    const int CKC = a.loader == LOADER_DEINT ? cv.CK / 2 : cv.CK;
+    const int nchunks = (Ctot + CKC - 1) / CKC;
+    int bfac;
+    const long long natural = conv_mtiles(a, v, TT, bfac) * ((a.N + NT - 1) / NT) * bfac;
+    const long long per = (long long)a.B * a.N * ((a.Tout + 3) & ~3);
+    return !(phase2 || ks > nchunks || natural * ks > 6144 || (long long)ks * per > part_cap);
+}
+
 // Candidate (tile variant, split-K) choices for the autotuner.  Returns the number written.
 int conv_list_candidates(const ConvArgs& a, long long part_cap, ConvChoice* out, int maxn) {
     int n = 0;
-    const int Ctot = a.C0 + a.C1;
-    const bool phase2 = (a.flags & F_PHASE2) != 0;
-    if ((a.N & 3) != 0) return 0;                                    // scalar-weight fallback: fixed menu
     const int nvar = (int)(sizeof(kConvVariants) / sizeof(kConvVariants[0]));
     static const int ks_menu[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48};
-    for (int v = 0; v < nvar && n < maxn; ++v) {
-        const ConvVariant& cv = kConvVariants[v];
-        if (Ctot <= 4 && cv.CK != 4) continue;
-        if (Ctot > 4 && cv.CK == 4 && (a.loader == LOADER_DEINT || phase2 || v < 26)) continue;
-        if (phase2 && !(cv.WN == 1 && (cv.NW % 2) == 0)) continue;
-        if (cv.fold && !conv_fold_ok(a, v)) continue;
-        const int TT = cv.WT * cv.MT * 16;
-        const int NT = phase2 ? cv.WN * cv.NW * 8 : cv.WN * cv.NW * 16;   // channels per workgroup
-        if (!cv.fold && TT > 16 && TT >= 2 * a.Tout) continue;       // mostly padding in time
-        if (cv.fold && (long long)TT >= 2ll * a.B * a.Tout) continue;
-        const int padded = ((a.N + NT - 1) / NT) * NT;
-        if (padded * 3 > a.N * 4 + 48) continue;                      // > ~33 % padded columns
-        if (conv_lds_bytes(a, v) > 150 * 1024) continue;
-        const int CKC = a.loader == LOADER_DEINT ? cv.CK / 2 : cv.CK;
-        const int nchunks = (Ctot + CKC - 1) / CKC;
-        int bfac;
-        const long long natural = conv_mtiles(a, v, TT, bfac) * ((a.N + NT - 1) / NT) * bfac;
-        const long long per = (long long)a.B * a.N * ((a.Tout + 3) & ~3);
+    for (int v = 0; v < nvar && n < maxn; ++v)
         for (unsigned i = 0; i < sizeof(ks_menu) / sizeof(ks_menu[0]) && n < maxn; ++i) {
-            const int ks = ks_menu[i];
-            if (ks > 1 && (phase2 || ks > nchunks || natural * ks > 6144 || (long long)ks * per > part_cap)) break;
-            out[n].variant = v; out[n].ksplit = ks; ++n;
+            if (!conv_choice_ok(a, part_cap, v, ks_menu[i])) break;  // larger splits fail the same bounds
+            out[n].variant = v; out[n].ksplit = ks_menu[i]; ++n;
         }
-    }
     return n;
 }
+
+int conv_num_variants() { return (int)(sizeof(kConvVariants) / sizeof(kConvVariants[0])); }
 
 // Vector (16-byte) paths need aligned bases / pitches; everything the plan allocates is.
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -914,6 +927,16 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 hipError_t launch_conv(const ConvArgs& a_in, float* part, long long part_cap, hipStream_t s) {
     ConvArgs a = a_in;
     if (conv_J(a) > WUN_JMAX) return hipErrorInvalidValue;       // rejected at plan creation
+    if (a.KW <= 0) {
+        // no taps (odd output phase of a transposed stride-2 conv with filter_size 1): the conv is the
+        // epilogue of an empty sum -- bias / activation / mask / accumulate through the split-K epilogue
+        const long long total = (long long)a.B * a.N * a.Tout;
+        if (total <= 0) return hipSuccess;
+        long long blocks = (total + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, 0);
+        return hipGetLastError();
+    }
     const bool vecw = (a.N & 3) == 0 && aligned16(a.W);
     bool vec = a.ostride == 1 && aligned16(a.dst0) && (a.obs0 & 3) == 0 && (a.opitch0 & 3) == 0 && (a.ooff0 & 3) == 0;
     if (a.dst1 != nullptr)
@@ -928,7 +951,10 @@ hipError_t launch_conv(const ConvArgs& a_in, float* part, long long part_cap, hi
     if (const char* e = getenv("WUN_NOVEC")) if (atoi(e)) a.flags &= ~F_VEC4;
 #endif
     int v = (a.flags & F_PHASE2) ? conv_pick_variant_phase2(a) : conv_pick_variant(a);
-    if (a.force_variant > 0 && vecw) v = a.force_variant - 1;
+    if (a.force_variant > 0 && vecw) {
+        v = a.force_variant - 1;
+        if (!conv_choice_ok(a, part != nullptr ? part_cap : 0, v, a.force_ksplit > 0 ? a.force_ksplit : 1)) return hipErrorInvalidValue;
+    }
 #ifdef WUN_ABLATION
     if (const char* e = getenv("WUN_VARIANT")) v = atoi(e);
 #endif

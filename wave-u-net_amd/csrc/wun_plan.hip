@@ -50,6 +50,14 @@ static int check_config(const wun_config* c) {
     if (c->num_channels != 1 && c->num_channels != 2) return fail(WUN_ERR_INVALID, "num_channels must be 1 or 2");
     if (c->num_sources < 1 || c->num_sources > 4) return fail(WUN_ERR_UNSUPPORTED, "num_sources must be 1..4");
     if (c->output_type == 1 && c->num_sources < 2) return fail(WUN_ERR_INVALID, "difference output needs >= 2 sources");
+    {
+        // the head kernels keep every source's output filter in LDS (default 64 KiB dynamic limit)
+        const long long sh = c->output_type == 0 ? c->num_sources : c->num_sources - 1;
+        const long long cin = (long long)c->num_channels + c->num_initial_filters;
+        const long long head_lds = 4 * sh * ((long long)c->output_filter_size * cin * c->num_channels + c->num_channels);
+        if (head_lds > 64 * 1024)
+            return fail(WUN_ERR_UNSUPPORTED, "output_filter_size x (num_channels + num_initial_filters) too large for the head kernels' LDS");
+    }
     return WUN_OK;
 }
 
@@ -522,7 +530,9 @@ static hipError_t conv_dispatch(const wun_plan* p, ConvArgs a, float* part, long
                     p->in_bwd ? "bwd" : "fwd", idx, a.C0 + a.C1, a.N, a.Tout, a.KW, a.loader, (a.flags & F_PHASE2) ? 1 : 0, n,
                     base, bc.variant, bc.ksplit, best);
     }
-    if (p->tune_mode >= 1 && idx < vec.size() && vec[idx].variant >= 0) {
+    if (p->tune_mode >= 1 && idx < vec.size() && vec[idx].variant >= 0 &&
+        conv_choice_ok(a, part ? cap : 0, vec[idx].variant, vec[idx].ksplit > 0 ? vec[idx].ksplit : 1)) {
+        // (an entry that is not a legal choice for this launch -- a stale or edited table -- is ignored)
         a.force_variant = vec[idx].variant + 1; a.force_ksplit = vec[idx].ksplit;
     }
     return launch_conv(a, part, cap, s);
@@ -715,8 +725,15 @@ static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const Conv
     }
     if (p->tune_mode >= 1 && idx < p->wg_bwd.size() && p->wg_bwd[idx].nsplit[0] > 0) {
         const WgradChoice& c = p->wg_bwd[idx];
-        if (wgrad_common_geom(parts, nparts, c.mtw, c.nw))
-            for (int i = 0; i < nparts; ++i) parts[i].nsplit = c.nsplit[i];
+        bool ok = (c.mtw == 1 || c.mtw == 2 || c.mtw == 4 || c.mtw == 6) && c.nw >= 1 && c.nw <= 5;
+        for (int i = 0; ok && i < nparts; ++i) ok = c.nsplit[i] >= 1;
+        WgradArgs g[2];
+        for (int i = 0; i < nparts; ++i) g[i] = parts[i];
+        if (ok && wgrad_common_geom(g, nparts, c.mtw, c.nw)) {
+            for (int i = 0; ok && i < nparts; ++i) ok = c.nsplit[i] <= wgrad_max_units(g[i]);
+            if (ok)
+                for (int i = 0; i < nparts; ++i) { parts[i] = g[i]; parts[i].nsplit = c.nsplit[i]; }
+        }
     }
     hipError_t e = run(parts);
     if (e == hipErrorOutOfMemory) return fail(WUN_ERR_INVALID, "internal: wgrad partial buffer too small");
@@ -939,19 +956,34 @@ extern "C" int wun_plan_tune(const wun_plan* p, const float* params, const float
     p->tune_mode = 1;
     int rc = wun_forward(p, params, mix_btc, ws, outputs, 1, stream);
     if (rc == WUN_OK) rc = wun_loss_backward(p, params, mix_btc, ws, outputs, targets, grads, loss, stream);
-    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    p->tune_mode = rc == WUN_OK ? 2 : 0;
+    const hipError_t sync = hipStreamSynchronize((hipStream_t)stream);
+    p->tune_mode = (rc == WUN_OK && sync == hipSuccess) ? 2 : 0;     // never left in measuring mode
+    if (rc == WUN_OK && sync != hipSuccess)
+        return fail(WUN_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(sync));
     return rc;
+}
+
+// Tuning-table header: identifies the plan (every config key that changes a launch), the launch
+// order of this library build and the number of entries per section, so a table written for
+// another plan, another library build or truncated on disk is rejected at import.
+#define WUN_TUNE_ORDER "r2a"      /* bump whenever the order / number of conv or wgrad launches changes */
+static std::string tune_header(const wun_plan* p, size_t ncf, size_t ncb, size_t nwg) {
+    char line[320];
+    const wun_config& c = p->cfg;
+    snprintf(line, sizeof(line),
+             "wun-tune 2 order=%s variants=%d B=%d Tin=%lld L=%d F=%d K=%d,%d,%d ups=%d out=%d ctx=%d S=%d C=%d act=%d "
+             "arena=%lld cf=%zu cb=%zu wg=%zu",
+             WUN_TUNE_ORDER, conv_num_variants(), p->B, (long long)p->Tin, p->L, c.num_initial_filters, c.filter_size,
+             c.merge_filter_size, c.output_filter_size, c.upsampling, c.output_type, c.context, c.num_sources,
+             c.num_channels, c.output_activation, (long long)p->arena, ncf, ncb, nwg);
+    return line;
 }
 
 extern "C" int wun_plan_tune_export(const wun_plan* p, char* buf, int64_t cap) {
     if (!p || !buf) return fail(WUN_ERR_INVALID, "null argument");
     if (p->tune_mode != 2) return fail(WUN_ERR_INVALID, "plan has not been tuned");
-    std::string out;
+    std::string out = tune_header(p, p->conv_fwd.size(), p->conv_bwd.size(), p->wg_bwd.size()) + "\n";
     char line[128];
-    snprintf(line, sizeof(line), "wun-tune 1 B=%d Tin=%lld L=%d F=%d arena=%lld\n", p->B, (long long)p->Tin, p->L,
-             p->cfg.num_initial_filters, (long long)p->arena);
-    out += line;
     auto dump = [&](const char* tag, const std::vector<ConvChoice>& v) {
         for (const ConvChoice& c : v) { snprintf(line, sizeof(line), "%s %d %d\n", tag, c.variant, c.ksplit); out += line; }
     };
@@ -961,6 +993,7 @@ extern "C" int wun_plan_tune_export(const wun_plan* p, char* buf, int64_t cap) {
         snprintf(line, sizeof(line), "wg %d %d %d %d\n", c.mtw, c.nw, c.nsplit[0], c.nsplit[1]);
         out += line;
     }
+    out += "end\n";
     if ((int64_t)out.size() + 1 > cap) return fail(WUN_ERR_INVALID, "buffer too small for the tuning table");
     memcpy(buf, out.c_str(), out.size() + 1);
     return WUN_OK;
@@ -968,17 +1001,25 @@ extern "C" int wun_plan_tune_export(const wun_plan* p, char* buf, int64_t cap) {
 
 extern "C" int wun_plan_tune_import(const wun_plan* p, const char* text) {
     if (!p || !text) return fail(WUN_ERR_INVALID, "null argument");
-    char want[128];
-    snprintf(want, sizeof(want), "wun-tune 1 B=%d Tin=%lld L=%d F=%d arena=%lld", p->B, (long long)p->Tin, p->L,
-             p->cfg.num_initial_filters, (long long)p->arena);
     const char* nl = strchr(text, '\n');
-    if (!nl || strncmp(text, want, strlen(want)) != 0 || (size_t)(nl - text) != strlen(want))
-        return fail(WUN_ERR_INVALID, "tuning table belongs to a different plan");
+    if (!nl) return fail(WUN_ERR_INVALID, "malformed tuning table");
+    const std::string head(text, (size_t)(nl - text));
+    size_t ncf = 0, ncb = 0, nwg = 0;
+    {
+        const size_t pos = head.rfind(" cf=");
+        if (pos == std::string::npos || sscanf(head.c_str() + pos, " cf=%zu cb=%zu wg=%zu", &ncf, &ncb, &nwg) != 3)
+            return fail(WUN_ERR_INVALID, "tuning table belongs to a different plan or library build");
+    }
+    if (head != tune_header(p, ncf, ncb, nwg))
+        return fail(WUN_ERR_INVALID, "tuning table belongs to a different plan or library build");
     std::vector<ConvChoice> cf, cb;
     std::vector<WgradChoice> wg;
     const char* q = nl + 1;
+    bool ended = false;
+    const int nvar = conv_num_variants();
     while (*q) {
         int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        if (strncmp(q, "end", 3) == 0) { ended = true; break; }
         if (sscanf(q, "cf %d %d", &a0, &a1) == 2 && q[1] == 'f') cf.push_back(ConvChoice{a0, a1});
         else if (sscanf(q, "cb %d %d", &a0, &a1) == 2 && q[1] == 'b') cb.push_back(ConvChoice{a0, a1});
         else if (sscanf(q, "wg %d %d %d %d", &a0, &a1, &a2, &a3) == 4) wg.push_back(WgradChoice{a0, a1, {a2, a3}});
@@ -987,6 +1028,16 @@ extern "C" int wun_plan_tune_import(const wun_plan* p, const char* text) {
         if (!e) break;
         q = e + 1;
     }
+    if (!ended || cf.size() != ncf || cb.size() != ncb || wg.size() != nwg)
+        return fail(WUN_ERR_INVALID, "truncated tuning table");
+    for (const std::vector<ConvChoice>* v : {&cf, &cb})
+        for (const ConvChoice& c : *v)
+            if (c.variant < -1 || c.variant >= nvar || c.ksplit < 0 || c.ksplit > 64)
+                return fail(WUN_ERR_INVALID, "tuning table entry out of range");
+    for (const WgradChoice& c : wg)
+        if (c.nsplit[0] < 0 || c.nsplit[1] < 0 || c.mtw < 0 || c.mtw > 6 || c.nw < 0 || c.nw > 5)
+            return fail(WUN_ERR_INVALID, "tuning table entry out of range");
+    // (whether each entry is a legal choice for the launch at its position is checked when it is used)
     p->conv_fwd = cf; p->conv_bwd = cb; p->wg_bwd = wg;
     p->tune_mode = 2;
     return WUN_OK;
@@ -1009,6 +1060,7 @@ extern "C" int wun_adam_step(const wun_plan* p, float* params, const float* grad
 // the single-operator entry points use a lazily allocated split-K scratch of their own
 static const long long kOpScratchFloats = 8ll << 20;
 static int g_op_variant = -1, g_op_ksplit = 0;          // wun_op_force_conv_variant (test hook)
+static int g_op_wg_mtw = 0, g_op_wg_nw = 0, g_op_wg_nsplit = 0;   // wun_op_force_wgrad_variant (test hook)
 static float* op_scratch() {
     static float* buf = nullptr;
     if (!buf && hipMalloc((void**)&buf, kOpScratchFloats * sizeof(float)) != hipSuccess) {
@@ -1019,7 +1071,7 @@ static float* op_scratch() {
 }
 
 static hipError_t op_launch_conv(ConvArgs a, hipStream_t s) {
-    if (g_op_variant >= 0 && !(a.flags & F_PHASE2)) { a.force_variant = g_op_variant + 1; a.force_ksplit = g_op_ksplit; }
+    if (g_op_variant >= 0) { a.force_variant = g_op_variant + 1; a.force_ksplit = (a.flags & F_PHASE2) ? 0 : g_op_ksplit; }
     return launch_conv(a, op_scratch(), kOpScratchFloats, s);
 }
 
@@ -1045,6 +1097,8 @@ extern "C" int wun_op_conv1d(const float* x, const float* w, const float* bias, 
     return WUN_OK;
 }
 
+static inline int pad4(int t) { return (t + 3) / 4 * 4; }
+
 static WgradArgs op_wgrad_args(const float* x, const float* dz, int batch, int cin, int cout, int k, int t_in,
                                int t_out, int stride, int pad_left, int xp, int zp) {
     WgradArgs w;
@@ -1056,13 +1110,19 @@ static WgradArgs op_wgrad_args(const float* x, const float* dz, int batch, int c
     return w;
 }
 
-static inline int pad4(int t) { return (t + 3) / 4 * 4; }
+// split partials of one loader kind under the current (possibly forced) geometry / split count
+static long long op_wgrad_part_floats(int batch, int cin, int cout, int k, int t_out, int loader) {
+    WgradArgs a = wgrad_shape_only(batch, cin, 0, k, loader, cout, t_out);
+    if (g_op_wg_mtw > 0) { a.force_mtw = g_op_wg_mtw; a.force_nw = g_op_wg_nw; }
+    long long ns = wgrad_pick_nsplit(a);
+    if (g_op_wg_nsplit > 0) ns = std::min(g_op_wg_nsplit, wgrad_max_units(a));
+    return ns * wgrad_partial_floats(a);
+}
 
 extern "C" int64_t wun_op_conv1d_wgrad_scratch(int batch, int cin, int cout, int k, int t_out) {
     // split partials (worst case over both loaders) + repacked copies of x (t_in <= 2*t_out + k) and dz
-    WgradArgs a = wgrad_shape_only(batch, cin, 0, k, LOADER_DIRECT, cout, t_out);
-    WgradArgs b = wgrad_shape_only(batch, cin, 0, k, LOADER_DEINT, cout, t_out);
-    const long long part = std::max(wgrad_pick_nsplit(a) * wgrad_partial_floats(a), wgrad_pick_nsplit(b) * wgrad_partial_floats(b));
+    const long long part = std::max(op_wgrad_part_floats(batch, cin, cout, k, t_out, LOADER_DIRECT),
+                                    op_wgrad_part_floats(batch, cin, cout, k, t_out, LOADER_DEINT));
     const long long tin_max = 2ll * t_out + k + 8;
     return part + (long long)batch * cin * pad4((int)tin_max) + (long long)batch * cout * pad4(t_out) + 512;
 }
@@ -1085,7 +1145,17 @@ extern "C" int wun_op_conv1d_wgrad(const float* x, const float* dz, float* dw, f
     HIP_TRY(hipMemcpy2DAsync(zs, (size_t)zp * 4, dz, (size_t)t_out * 4, (size_t)t_out * 4, (size_t)batch * cout,
                              hipMemcpyDeviceToDevice, s));
     WgradArgs w = op_wgrad_args(xs, zs, batch, cin, cout, k, t_in, t_out, stride, pad_left, xp, zp);
+    if (g_op_wg_mtw > 0) {
+        w.force_mtw = g_op_wg_mtw; w.force_nw = g_op_wg_nw;
+        int m, n;
+        wgrad_resolved_geom(w, m, n);
+        if (m != g_op_wg_mtw || n != g_op_wg_nw)
+            return fail(WUN_ERR_UNSUPPORTED, "forced weight-gradient tile geometry is not available for this shape");
+    }
     w.nsplit = wgrad_pick_nsplit(w);
+    if (g_op_wg_nsplit > 0) {
+        w.nsplit = std::min(g_op_wg_nsplit, wgrad_max_units(w));
+    }
     part = (float*)(((uintptr_t)part + 255) & ~(uintptr_t)255);
     w.out = part; w.direct = 0; w.split_base = 0;      // always through the split reduction (dw and db are separate buffers)
     HIP_TRY(launch_wgrad(w, s));
@@ -1146,6 +1216,36 @@ extern "C" int wun_op_conv1d_dgrad(const float* dz, const float* w, float* dx, f
 
 extern "C" int wun_op_force_conv_variant(int variant, int ksplit) {
     g_op_variant = variant; g_op_ksplit = ksplit;
+    return WUN_OK;
+}
+
+extern "C" int wun_op_num_conv_variants(void) { return conv_num_variants(); }
+
+extern "C" int wun_op_force_wgrad_variant(int mtw, int nw, int nsplit) {
+    g_op_wg_mtw = mtw; g_op_wg_nw = nw; g_op_wg_nsplit = nsplit;
+    return WUN_OK;
+}
+
+// General form of the conv launch the plan uses: virtual channel-concat of two sources (crop_and_concat,
+// Utils.py:11-24), accumulate into the destination, LeakyReLU-derivative mask, output stride / offset.
+extern "C" int wun_op_conv1d_ex(const float* x0, int c0, const float* x1, int c1, const float* w, const float* bias,
+                                float* y, const float* mask, int batch, int cout, int k, int t_in, int t_out,
+                                int t_y, int stride, int pad_left, int lrelu, int accumulate, int ostride, int ooff,
+                                void* stream) {
+    if (!x0 || !w || !y) return fail(WUN_ERR_INVALID, "null argument");
+    if (stride != 1 && stride != 2) return fail(WUN_ERR_UNSUPPORTED, "stride must be 1 or 2");
+    if (c0 < 1 || c1 < 0 || (c1 > 0 && !x1)) return fail(WUN_ERR_INVALID, "bad source channels");
+    if (ostride < 1 || ooff < 0 || (long long)(t_out - 1) * ostride + ooff >= t_y) return fail(WUN_ERR_INVALID, "output does not fit t_y");
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = batch; a.ostride = ostride;
+    a.src0 = x0; a.bs0 = (long long)c0 * t_in; a.pitch0 = t_in; a.C0 = c0;
+    if (c1 > 0) { a.src1 = x1; a.bs1 = (long long)c1 * t_in; a.pitch1 = t_in; a.C1 = c1; }
+    a.loader = stride == 2 ? LOADER_DEINT : LOADER_DIRECT;
+    a.Tin = t_in; a.shift = pad_left; a.W = w; a.bias = bias; a.KW = k; a.N = a.N0 = cout; a.Tout = t_out;
+    a.flags = (lrelu ? F_LRELU : 0) | (accumulate ? F_ACCUM : 0);
+    a.dst0 = y; a.obs0 = (long long)cout * t_y; a.opitch0 = t_y; a.ooff0 = ooff; a.msk0 = mask;
+    HIP_TRY(op_launch_conv(a, (hipStream_t)stream));
     return WUN_OK;
 }
 

@@ -14,6 +14,7 @@ import time
 
 import numpy as np
 import torch
+import torch.distributed as dist
 
 from .parallel import GradAllReducer, OverlappedGradAllReducer, broadcast_parameters, init_distributed
 from .separator import UnetAudioSeparator
@@ -68,22 +69,39 @@ class Trainer(object):
         self.lr = model_config["init_sup_sep_lr"]
 
     def tune(self, mix, targets):
-        """One-off kernel autotuning on a real batch (skipped with WUN_NO_TUNE=1).  With
-        WUN_TUNE_CACHE=<file> the choices are read from / written to that file, so later processes
-        (profilers, restarts) run the same tilings without re-tuning."""
+        """One-off kernel autotuning on a real batch (skipped with WUN_NO_TUNE=1).  Rank 0 decides
+        the tilings -- from WUN_TUNE_CACHE=<file> if it holds a table for this plan and library
+        build, else by measuring (wun_plan_tune) -- and broadcasts the exported table; every rank
+        imports that same table, so all replicas run bit-identical kernels (per-rank tuning would
+        let replicas differ by fp32 rounding before the gradient all-reduce) and nobody reads a
+        cache file that another rank is still writing.  The cache is written atomically."""
         if os.environ.get("WUN_NO_TUNE") is not None:
             return
         cache = os.environ.get("WUN_TUNE_CACHE")
-        if cache and os.path.exists(cache):
-            try:
-                self.sep.tune_import(open(cache).read())
-                return
-            except ValueError:
-                pass                                     # other shape / config: tune afresh
-        self.sep.tune(mix, targets)
-        if cache and self.rank == 0:
-            with open(cache, "w") as f:
-                f.write(self.sep.tune_export())
+        self.sep.get_output(mix, True)                    # makes this (batch, length) plan the active one
+        table = None
+        if self.rank == 0:
+            if cache and os.path.exists(cache):
+                try:
+                    text = open(cache).read()
+                    self.sep.tune_import(text)
+                    table = text
+                except ValueError:
+                    table = None                         # other plan / library build / truncated: tune afresh
+            if table is None:
+                self.sep.tune(mix, targets)
+                table = self.sep.tune_export()
+                if cache:
+                    tmp = "%s.tmp.%d" % (cache, os.getpid())
+                    with open(tmp, "w") as f:
+                        f.write(table)
+                    os.replace(tmp, cache)
+        if self.world > 1:
+            box = [table]
+            dist.broadcast_object_list(box, src=0)
+            if self.rank != 0:
+                self.sep.tune_import(box[0])
+        self.tune_table = table if self.rank == 0 else box[0]
 
     def step(self, mix, targets):
         self.sep.get_output(mix, True)
@@ -108,12 +126,22 @@ def train(model_config, experiment_id, load_model=None, batch_source=None, log_e
         log_every = 100 if model_config["epoch_it"] > 100 else 1
     tr = Trainer(model_config)
     if load_model is not None:
-        state = np.load(load_model)
-        tr.sep.load_variables({k: state[k] for k in state.files if k.startswith("separator/")})
-        if "adam_m" in state.files:
-            tr.sep.adam_m.copy_(torch.from_numpy(state["adam_m"]))
-            tr.sep.adam_v.copy_(torch.from_numpy(state["adam_v"]))
-        tr.sep.global_step = int(state["global_step"])
+        # rank 0 reads the checkpoint (the only rank that is guaranteed to have the path: train()
+        # hands save_path to every rank, but the file system need not be shared); parameters, both
+        # Adam slots and global_step are then broadcast so every replica resumes the SAME state
+        if tr.rank == 0:
+            state = np.load(load_model)
+            tr.sep.load_variables({k: state[k] for k in state.files if k.startswith("separator/")})
+            if "adam_m" in state.files:
+                tr.sep.adam_m.copy_(torch.from_numpy(state["adam_m"]))
+                tr.sep.adam_v.copy_(torch.from_numpy(state["adam_v"]))
+            tr.sep.global_step = int(state["global_step"])
+        if tr.world > 1:
+            for t in (tr.sep.params, tr.sep.adam_m, tr.sep.adam_v):
+                broadcast_parameters(t)
+            box = [tr.sep.global_step]
+            dist.broadcast_object_list(box, src=0)
+            tr.sep.global_step = int(box[0])
     if batch_source is None:
         batch_source = synthetic_source(model_config, tr.batch, tr.t_in, tr.t_out, tr.device,
                                         seed=1337 + tr.rank)
@@ -144,4 +172,10 @@ def train(model_config, experiment_id, load_model=None, batch_source=None, log_e
         arrays["global_step"] = np.int64(tr.sep.global_step)
         np.savez(save_path, **arrays)
         log.close()
+    if tr.world > 1:
+        # every rank returns the checkpoint path (Training.py:121 has one process; here the callers --
+        # optimise()'s next epoch, test() -- run on all ranks and must agree on it)
+        box = [save_path]
+        dist.broadcast_object_list(box, src=0)
+        save_path = box[0]
     return save_path

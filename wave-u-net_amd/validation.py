@@ -81,7 +81,7 @@ def optimise(model_config, experiment_id, data=None, data_root=None, max_epochs=
                 break
             model_path = train(model_config, experiment_id, load_model=model_path,
                                batch_source=_train_source(model_config, data["train"], seed=1337 + epoch))
-            curr_loss = test(model_config, "valid", str(experiment_id), model_path, tracks=data["valid"])
+            curr_loss = _rank0_test(model_config, "valid", str(experiment_id), model_path, data["valid"])
             epoch += 1
             if curr_loss < best_loss:
                 worse_epochs = 0
@@ -89,8 +89,24 @@ def optimise(model_config, experiment_id, data=None, data_root=None, max_epochs=
                 best_loss = curr_loss
             else:
                 worse_epochs += 1
-    test_loss = test(model_config, "test", str(experiment_id), best_model_path, tracks=data["test"])
+    test_loss = _rank0_test(model_config, "test", str(experiment_id), best_model_path, data["test"])
     return best_model_path, test_loss
+
+
+def _rank0_test(model_config, partition, model_folder, load_model, tracks):
+    """test() on rank 0 only, its loss broadcast to every rank: the early-stopping decisions of
+    optimise() (worse_epochs, best checkpoint, loop exit) are then identical on all ranks -- ranks
+    that disagreed would leave the next epoch's gradient all-reduce waiting forever."""
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    loss = None
+    if not multi or dist.get_rank() == 0:
+        loss = test(model_config, partition, model_folder, load_model, tracks=tracks)
+    if multi:
+        box = [loss]
+        dist.broadcast_object_list(box, src=0)
+        loss = box[0]
+    return loss
 
 
 def _train_source(model_config, tracks, seed):
