@@ -64,6 +64,16 @@ GOLDEN_CASES = {
                                             merge_filter_size=2, input_filter_size=4,
                                             output_filter_size=2), batch=1, frames=32, seed=21,
                                    training=True),
+    # input_filter_size != filter_size: get_padding sizes layer 0 with input_filter_size
+    # (UnetAudioSeparator.py:73) but get_output convolves it with filter_size (:98), so the graph's
+    # output length differs from get_padding's answer -- the reference's behaviour, reproduced as is
+    "input_filter_mismatch_small": dict(cfg=dict(_SMALL, output_type="difference", context=True,
+                                                 filter_size=7, input_filter_size=11, merge_filter_size=3),
+                                        batch=2, frames=40, seed=22, training=True),
+    # filter_size 1 with context: the transposed stride-2 conv's odd output phase has no taps
+    "filter1_context_small": dict(cfg=dict(_SMALL, output_type="difference", context=True, filter_size=1,
+                                           input_filter_size=1, merge_filter_size=3, mono_downmix=False),
+                                  batch=2, frames=40, seed=23, training=True),
     # full-size M1 (Config.py:15-33), one excerpt
     "M1_full": dict(cfg=dict(), batch=1, frames=16384, seed=31, training=True),
     # full-size M1 architecture with context (BASELINE.json configs[1] shape), one excerpt

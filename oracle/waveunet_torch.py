@@ -257,3 +257,40 @@ def synthetic_batch(cfg, batch, t_in, t_out, seed=1337):
     targets = {n: (s[:, pad:t_in - pad, :] if pad > 0 else s).copy()
                for n, s in zip(cfg["source_names"], srcs)}
     return mix, targets
+
+
+def chunked_train_step(cfg, named_params, mix_btc, targets, dtype=torch.float32, chunk=1, want_outputs=False,
+                       timings=None):
+    """Loss and gradients of a whole batch, computed `chunk` excerpts at a time so that a full-size
+    batch (16 x 147443 samples) never holds more than one chunk's autograd graph in host memory.
+    The loss is a mean over excerpts (Training.py:62), so batch loss / gradient = mean of the
+    chunk losses / gradients (equal chunk sizes are required).  named_params: [(tf_name, ndarray)].
+    Returns (loss float, [grad tensors in variable order], {source: [B,Tout,C]} or None).
+    `timings`, if a list, receives the wall time of each chunk's forward+backward."""
+    import time
+    cfg = shapes.finalize_config(cfg)
+    B = mix_btc.shape[0]
+    assert B % chunk == 0, (B, chunk)
+    tp = params_to_torch(named_params, dtype, requires_grad=True)
+    acc, loss_sum, outs = None, 0.0, ({n: [] for n in cfg["source_names"]} if want_outputs else None)
+    for lo in range(0, B, chunk):
+        t0 = time.time()
+        tmix = torch.as_tensor(mix_btc[lo:lo + chunk]).to(dtype)
+        ttg = {k: torch.as_tensor(v[lo:lo + chunk]).to(dtype) for k, v in targets.items()}
+        for _, p in tp:
+            p.grad = None
+        o = get_output(cfg, tp, tmix, True)
+        loss = separator_loss(cfg, o, ttg)
+        loss.backward()
+        if timings is not None:
+            timings.append(time.time() - t0)
+        loss_sum += float(loss.detach())
+        g = [p.grad.detach().double() for _, p in tp]
+        acc = g if acc is None else [a + b for a, b in zip(acc, g)]
+        if want_outputs:
+            for n in cfg["source_names"]:
+                outs[n].append(o[n].detach())
+    n = B // chunk
+    if want_outputs:
+        outs = {k: torch.cat(v, dim=0) for k, v in outs.items()}
+    return loss_sum / n, [a / n for a in acc], outs

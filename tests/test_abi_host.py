@@ -64,6 +64,11 @@ def test_plan_tables_match_oracle(name, lib):
     assert plan.info.output_frames == lt["t_out"]
     if ocfg["context"]:
         assert plan.info.output_frames == o[1]
+        # (input_filter_size != filter_size -- UnetAudioSeparator.py:73 vs :98: the graph ignores
+        # input_filter_size, the surplus input is absorbed by uneven skip crops, Utils.py:120-121;
+        # the golden of that case pins the resulting numbers)
+        g = np.load(os.path.join(ROOT, "tests", "golden", "fwd_%s.npz" % name))
+        assert plan.info.output_frames == g["out_" + ocfg["source_names"][0]].shape[1]
     want = shapes.variable_table(ocfg)
     got = [(n, list(s)) for n, _, s in plan.tensors]
     assert got == [(n, list(s)) for n, s in want]
@@ -74,8 +79,10 @@ def test_plan_tables_match_oracle(name, lib):
         off += int(np.prod(s))
     assert plan.info.arena_floats == off == plan.info.num_params == shapes.num_params(ocfg)
     assert plan.info.workspace_floats > 0
+    # dead-work skipping never executes more than the dense graph (except for 1-tap filters, where
+    # the stride-2 + crop-window split has no halo to save and the two parts overlap)
     assert plan.info.fwd_flops <= plan.info.fwd_flops_dense + 1e-6 * plan.info.fwd_flops_dense \
-        or not ocfg["context"]
+        or not ocfg["context"] or ocfg["filter_size"] < 3
 
 
 def test_m1_sizes_and_flops():

@@ -126,3 +126,108 @@ def test_cli_argument_parsing():
     assert over == {"epoch_it": 7, "upsampling": "linear"} and opts == {"data_root": "/x", "experiment_id": 3}
     with pytest.raises(SystemExit):
         cli._parse(["frobnicate"])
+
+
+# ---------------------------------------------------------------------------------------------
+# the producers against the line-by-line restatement of the reference pipeline (oracle/datasets_np.py)
+# ---------------------------------------------------------------------------------------------
+class _RecordingRng(object):
+    """numpy Generator that logs every random decision the product's pipeline takes, by kind."""
+
+    def __init__(self, seed):
+        self.rng = np.random.default_rng(seed)
+        self.order, self.pos, self.gain, self.picks = [], [], [], []
+
+    def permutation(self, n):
+        r = self.rng.permutation(n)
+        self.order.append([int(v) for v in r])
+        return r
+
+    def integers(self, lo, hi, size=None, dtype=np.int64):
+        r = self.rng.integers(lo, hi, size=size, dtype=dtype)
+        if size is None:
+            self.picks.append(int(r))
+        else:
+            self.pos.extend(int(v) for v in r)
+        return r
+
+    def uniform(self, lo, hi, size=None):
+        r = self.rng.uniform(lo, hi, size=size)
+        self.gain.extend(np.atleast_1d(r).astype(np.float32).tolist())
+        return r
+
+    def shuffle(self, x):
+        self.rng.shuffle(x)
+
+
+class _Replay(object):
+    """The `decisions` object of oracle/datasets_np.py, answering from a recording."""
+
+    def __init__(self, rec):
+        self.order, self.pos, self.gains, self.picks = list(rec.order), list(rec.pos), list(rec.gain), list(rec.picks)
+
+    def file_order(self, n):
+        o = self.order.pop(0)
+        assert sorted(o) == list(range(n))
+        return o
+
+    def positions(self, maxval, num):
+        out, self.pos = self.pos[:num], self.pos[num:]
+        assert len(out) == num and all(0 <= p < maxval for p in out)          # tf.random_uniform(0, maxval)
+        return out
+
+    def gain(self):
+        g = self.gains.pop(0)
+        assert 0.7 <= g <= 1.0
+        return g
+
+    def pick(self, buffer_size):
+        i = self.picks.pop(0)
+        assert 0 <= i < buffer_size
+        return i
+
+
+@pytest.mark.parametrize("config,partition,augment", [("baseline", "train", True), ("full_multi_instrument", "train", True),
+                                                      ("baseline_stereo", "train", False), ("full", "valid", False)])
+def test_host_pipeline_equals_the_reference_restatement(config, partition, augment):
+    """get_dataset() vs oracle/datasets_np.py (Datasets.py:188-216 + Utils.py:26-42 restated line by
+    line) under the SAME random decisions: bit-identical batches."""
+    from oracle import datasets_np
+    cfg = wun.get_config(config, batch_size=4, num_snippets_per_track=3, cache_size=7, augmentation=augment)
+    C = 1 if cfg["mono_downmix"] else 2
+    t_in, t_out = 90, 40
+    tracks = _tracks(cfg, [400, 257, 333], seed=4)
+    rec = _RecordingRng(11)
+    gen = datasets.get_dataset(cfg, [4, t_in, C], [4, t_out, C], partition, tracks, rng=rec)
+    nb = 9 if partition == "train" else 10 ** 6
+    got = []
+    for b in gen:
+        got.append(b)
+        if len(got) == nb:
+            break
+    want = datasets_np.get_dataset(cfg, [4, t_in, C], [4, t_out, C], partition, tracks, _Replay(rec), len(got))
+    assert len(want) == len(got) >= 2
+    for g, w in zip(got, want):
+        assert sorted(g) == sorted(w)
+        for k in g:
+            assert g[k].dtype == np.float32 and g[k].shape == w[k].shape
+            assert np.array_equal(g[k], w[k]), k
+    if partition == "train":
+        assert len(rec.order) >= 2 and len(rec.picks) > 0          # more than one pass, buffer in use
+
+
+def test_device_source_delivers_the_host_pipelines_batches():
+    """DeviceSnippetSource (gather + gain + sum + crop on the device) == get_dataset(train) for the same
+    seed, bit for bit (device "cpu" here; tests/test_validation_gpu.py runs it on the GPU)."""
+    import torch
+    cfg = wun.get_config("full_multi_instrument", batch_size=4, num_snippets_per_track=3, cache_size=5)
+    t_in, t_out = 90, 40
+    tracks = _tracks(cfg, [400, 257, 333], seed=6)
+    gen = datasets.get_dataset(cfg, [4, t_in, 2], [4, t_out, 2], "train", tracks, seed=21)
+    src = datasets.DeviceSnippetSource(cfg, tracks, t_in, t_out, 4, "cpu", seed=21)
+    for _ in range(6):
+        hb = next(gen)
+        mix, targets = src()
+        assert torch.equal(mix, torch.from_numpy(hb["mix"]))
+        for si, name in enumerate(cfg["source_names"]):
+            assert torch.equal(targets[si], torch.from_numpy(hb[name])), name

@@ -2,10 +2,12 @@
 (libwun.so via wave_u_net_amd), against the oracle on the same seeded inputs and against
 the committed goldens generated from the reference's own graph code.
 
-Tolerances (fp32 path, stated per BASELINE.json north_star "within a stated fp32
-tolerance"): single ops 1e-4 * max|ref|; network outputs 2e-4 absolute (outputs are O(1));
-loss 1e-5 relative; gradients 2e-3 * max|grad tensor| + 1e-7 (fp32 reductions over up to
-2.4M positions vs float64 oracle)."""
+Tolerances (fp32 path, stated per BASELINE.json north_star "within a stated fp32 tolerance";
+every comparison also LOGS the error it observed -- tests/_observed.py -- and the tolerances
+below are kept within ~10x of those observations):
+single ops OP_TOL * max|ref|; network outputs OUT_TOL absolute (outputs are O(1)); loss LOSS_TOL
+relative; gradients GRAD_TOL * max|grad tensor| + 1e-7 per tensor against the FLOAT64 oracle at
+every size, including full size (<= 1e-3)."""
 import ctypes as C
 import os
 
@@ -16,8 +18,14 @@ import torch.nn.functional as F
 
 from oracle import shapes, waveunet_torch as wt
 from oracle.golden_params import GOLDEN_CASES, golden_params
+from _observed import record
 
 pytestmark = pytest.mark.gpu
+
+OP_TOL = 2e-5        # x max|ref|
+OUT_TOL = 5e-5       # absolute, outputs are O(1)
+LOSS_TOL = 1e-5      # relative
+GRAD_TOL = 1e-3      # x max|g| per tensor, vs the float64 oracle
 
 import wave_u_net_amd as wun                      # noqa: E402
 from wave_u_net_amd import _lib                   # noqa: E402
@@ -121,7 +129,9 @@ def test_op_conv1d_forward(lib, case):
     ref = _conv_ref(x, w, b, stride, pad, t_out, True)
     got = y.cpu().numpy()
     assert np.isfinite(got).all()
-    assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+    err = np.abs(got - ref).max() / max(1.0, np.abs(ref).max())
+    record("op_conv1d_forward", str(case), err, OP_TOL)
+    assert err <= OP_TOL
 
 
 FOLD_CASES = [
@@ -167,15 +177,17 @@ def test_op_conv1d_every_fold_variant(lib, case):
                 torch.cuda.synchronize()
                 got = y.cpu().numpy()
                 assert np.isfinite(got).all(), (variant, ks)
-                assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (variant, ks)
+                assert np.abs(got - ref).max() <= OP_TOL * max(1.0, np.abs(ref).max()), (variant, ks)
+                ran += 1
                 gdx = torch.full((B, Cin, T), float("nan"), device="cuda")
-                _lib.check(lib.wun_op_conv1d_dgrad(dzg.data_ptr(), dw.data_ptr(), gdx.data_ptr(), wts.data_ptr(), B, Cin,
-                                                   Cout, K, T, t_out, stride, pad, _stream()))
+                rc = lib.wun_op_conv1d_dgrad(dzg.data_ptr(), dw.data_ptr(), gdx.data_ptr(), wts.data_ptr(), B, Cin,
+                                             Cout, K, T, t_out, stride, pad, _stream())
+                if rc != 0:
+                    continue               # not a legal choice for the transposed shape (N = Cin)
                 torch.cuda.synchronize()
                 gd = gdx.cpu().numpy()
                 assert np.isfinite(gd).all(), (variant, ks)
-                assert np.abs(gd - ref_dx).max() <= 1e-4 * max(1.0, np.abs(ref_dx).max()), (variant, ks)
-                ran += 1
+                assert np.abs(gd - ref_dx).max() <= OP_TOL * max(1.0, np.abs(ref_dx).max()), (variant, ks)
     finally:
         lib.wun_op_force_conv_variant(-1, 0)
     assert ran >= 4
@@ -207,8 +219,10 @@ def test_op_conv1d_wgrad_and_dgrad(lib, case):
     _lib.check(lib.wun_op_conv1d_wgrad(dxg.data_ptr(), dzg.data_ptr(), gdw.data_ptr(), gdb.data_ptr(),
                                        scr.data_ptr(), B, Cin, Cout, K, T, t_out, stride, pad, _stream()))
     torch.cuda.synchronize()
-    assert np.abs(gdw.cpu().numpy() - ref_dw).max() <= 1e-4 * max(1.0, np.abs(ref_dw).max())
-    assert np.abs(gdb.cpu().numpy() - ref_db).max() <= 1e-4 * max(1.0, np.abs(ref_db).max())
+    ew = np.abs(gdw.cpu().numpy() - ref_dw).max() / max(1.0, np.abs(ref_dw).max())
+    eb = np.abs(gdb.cpu().numpy() - ref_db).max() / max(1.0, np.abs(ref_db).max())
+    record("op_conv1d_wgrad", str(case), max(ew, eb), OP_TOL)
+    assert ew <= OP_TOL and eb <= OP_TOL
 
     if stride == 2 and pad != 0:
         return
@@ -219,7 +233,9 @@ def test_op_conv1d_wgrad_and_dgrad(lib, case):
     torch.cuda.synchronize()
     got = gdx.cpu().numpy()
     assert np.isfinite(got).all()
-    assert np.abs(got - ref_dx).max() <= 1e-4 * max(1.0, np.abs(ref_dx).max())
+    err = np.abs(got - ref_dx).max() / max(1.0, np.abs(ref_dx).max())
+    record("op_conv1d_dgrad", str(case), err, OP_TOL)
+    assert err <= OP_TOL
 
 
 def _ocfg(case):
@@ -252,26 +268,50 @@ def test_forward_matches_reference_goldens(lib, name, golden_dir):
         ref = g["out_" + n]
         assert got.shape == ref.shape
         assert np.isfinite(got).all(), n
-        assert np.abs(got - ref).max() <= 2e-4, (n, np.abs(got - ref).max())
+        record("forward_vs_reference_goldens", "%s/%s" % (name, n), np.abs(got - ref).max(), OUT_TOL)
+        assert np.abs(got - ref).max() <= OUT_TOL, (n, np.abs(got - ref).max())
 
 
 STEP_CASES = ["baseline_small", "baseline_diff_small", "baseline_context_small", "baseline_stereo_small",
               "full_small", "full_multi_small", "learned_same_small", "odd_filters_small",
-              "odd_filters_same_small"]
+              "odd_filters_same_small", "input_filter_mismatch_small", "filter1_context_small"]
 
 
-def _grad_check(sep, tp, ograds, tol=2e-3):
+def _grad_check(sep, tp, ograds, tol=GRAD_TOL, tag="?"):
+    """Every gradient tensor against the (float64) oracle: max|got - ref| <= tol * max|ref| + 1e-7."""
     g = sep.gradients()
     worst = []
     for (n, _), og in zip(tp, ograds):
         got = g[n].cpu().double()
+        og = og.double()
         scale = max(og.abs().max().item(), 1e-30)
         err = (got - og).abs().max().item()
-        worst.append((err / scale, n, err, scale))
+        worst.append((max(0.0, err - 1e-7) / scale, n, err, scale))
         assert torch.isfinite(got).all(), n
     worst.sort(reverse=True)
+    record("gradients_vs_float64_oracle", "%s (worst: %s)" % (tag, worst[0][1]), worst[0][0], tol)
     bad = [w for w in worst if w[2] > tol * w[3] + 1e-7]
     assert not bad, bad[:5]
+
+
+def _loss_check(loss, oloss, tag):
+    rel = abs(float(loss) - float(oloss)) / max(abs(float(oloss)), 1e-3)
+    record("loss_vs_float64_oracle", tag, rel, LOSS_TOL)
+    assert rel <= LOSS_TOL, (float(loss), float(oloss))
+
+
+def _out_check(outs, oouts, names, tag):
+    worst = max((outs[n].cpu().double() - oouts[n].detach().double()).abs().max().item() for n in names)
+    record("outputs_vs_float64_oracle", tag, worst, OUT_TOL)
+    assert worst <= OUT_TOL, worst
+
+
+def _oracle64(ocfg, params, mix, targets, chunk=1):
+    """float64 oracle of a whole batch, one chunk of excerpts at a time (bounded host memory)."""
+    loss, grads, outs = wt.chunked_train_step(ocfg, params, mix, targets, dtype=torch.float64, chunk=chunk,
+                                              want_outputs=True)
+    tp = [(n, None) for n, _ in params]
+    return loss, grads, outs, tp
 
 
 @pytest.mark.parametrize("name", STEP_CASES)
@@ -295,10 +335,9 @@ def test_train_step_matches_oracle(lib, name):
     ttg = {k: torch.tensor(v, dtype=torch.float64) for k, v in targets.items()}
     oloss, ograds = wt.train_step(ocfg, tp, tmix, ttg)
     oouts = wt.get_output(ocfg, tp, tmix, True)
-    for n in ocfg["source_names"]:
-        assert (outs[n].cpu().double() - oouts[n].detach()).abs().max().item() <= 2e-4, n
-    assert abs(loss.item() - oloss.item()) <= 1e-5 * max(abs(oloss.item()), 1e-3)
-    _grad_check(sep, tp, ograds)
+    _out_check(outs, oouts, ocfg["source_names"], name)
+    _loss_check(loss.item(), oloss.item(), name)
+    _grad_check(sep, tp, ograds, tag=name)
 
     # one TF-rule Adam update: the kernel vs the oracle's tf_adam_step fed with the SAME (GPU)
     # gradients, so this isolates the optimizer arithmetic from gradient round-off
@@ -336,10 +375,10 @@ def test_full_size_m1_context_step_vs_oracle(lib):
     outs = sep.get_output(torch.from_numpy(mix).cuda(), True)
     loss = sep.loss_and_gradients({k: torch.from_numpy(v) for k, v in targets.items()})
     torch.cuda.synchronize()
-    tp = wt.params_to_torch(params, torch.float32, requires_grad=True)
-    oloss, ograds = wt.train_step(ocfg, tp, torch.from_numpy(mix), {k: torch.from_numpy(v) for k, v in targets.items()})
-    assert abs(loss.item() - oloss.item()) <= 2e-5 * abs(oloss.item())
-    _grad_check(sep, tp, [g.double() for g in ograds], tol=5e-3)
+    oloss, ograds, oouts, tp = _oracle64(ocfg, params, mix, targets)
+    _out_check(outs, oouts, ocfg["source_names"], "M1_context_full_B2")
+    _loss_check(loss.item(), oloss, "M1_context_full_B2")
+    _grad_check(sep, tp, ograds, tag="M1_context_full_B2")
 
 
 def test_full_size_m1_same_step_vs_oracle(lib):
@@ -351,13 +390,13 @@ def test_full_size_m1_same_step_vs_oracle(lib):
     mix, targets = wt.synthetic_batch(ocfg, B, 16384, 16384, seed=80)
     sep._plan(B, 16384); sep._active = sep._plans[(B, 16384)]
     sep.load_variables(params)
-    sep.get_output(torch.from_numpy(mix).cuda(), True)
+    outs = sep.get_output(torch.from_numpy(mix).cuda(), True)
     loss = sep.loss_and_gradients({k: torch.from_numpy(v) for k, v in targets.items()})
     torch.cuda.synchronize()
-    tp = wt.params_to_torch(params, torch.float32, requires_grad=True)
-    oloss, ograds = wt.train_step(ocfg, tp, torch.from_numpy(mix), {k: torch.from_numpy(v) for k, v in targets.items()})
-    assert abs(loss.item() - oloss.item()) <= 2e-5 * abs(oloss.item())
-    _grad_check(sep, tp, [g.double() for g in ograds], tol=5e-3)
+    oloss, ograds, oouts, tp = _oracle64(ocfg, params, mix, targets)
+    _out_check(outs, oouts, ocfg["source_names"], "M1_same_full_B2")
+    _loss_check(loss.item(), oloss, "M1_same_full_B2")
+    _grad_check(sep, tp, ograds, tag="M1_same_full_B2")
 
 
 def test_full_batch_properties_m1_context(lib):
@@ -482,18 +521,15 @@ def test_full_size_named_configs_step_vs_oracle(lib, name):
     outs = sep.get_output(torch.from_numpy(mix).cuda(), True)
     loss = sep.loss_and_gradients({k: torch.from_numpy(v) for k, v in targets.items()})
     torch.cuda.synchronize()
-    tp = wt.params_to_torch(params, torch.float32, requires_grad=True)
     tmix = torch.from_numpy(mix)
-    oloss, ograds = wt.train_step(ocfg, tp, tmix, {k: torch.from_numpy(v) for k, v in targets.items()})
-    oouts = wt.get_output(ocfg, tp, tmix, True)
-    for n in ocfg["source_names"]:
-        assert (outs[n].cpu() - oouts[n].detach()).abs().max().item() <= 2e-4, n
+    oloss, ograds, oouts, tp = _oracle64(ocfg, params, mix, targets)
+    _out_check(outs, oouts, ocfg["source_names"], name)
     # difference output: the sources add up to the cropped mix (OutputLayer.py:20-22)
     total = sum(outs[n] for n in ocfg["source_names"]).cpu()
     pad = (i[1] - o[1]) // 2
     assert (total - tmix[:, pad:i[1] - pad, :]).abs().max().item() <= 1e-5
-    assert abs(loss.item() - oloss.item()) <= 2e-5 * abs(oloss.item())
-    _grad_check(sep, tp, [g.double() for g in ograds], tol=5e-3)
+    _loss_check(loss.item(), oloss, name)
+    _grad_check(sep, tp, ograds, tag=name)
 
 
 def test_deep_variant_16_levels_48_filters(lib):
@@ -515,13 +551,15 @@ def test_deep_variant_16_levels_48_filters(lib):
     loss = sep.loss_and_gradients({k: torch.from_numpy(v) for k, v in targets.items()})
     torch.cuda.synchronize()
     assert torch.isfinite(sep.grads).all()
+    # the one comparison against the FLOAT32 oracle: its float64 backward of this 92 M-parameter,
+    # 590 k-sample graph needs tens of GB of host memory; the fp32 oracle's own rounding is part of
+    # the observed error here, hence the wider gradient tolerance
     tp = wt.params_to_torch(params, torch.float32, requires_grad=True)
     oloss, ograds = wt.train_step(ocfg, tp, torch.from_numpy(mix), {k: torch.from_numpy(v) for k, v in targets.items()})
     oouts = wt.get_output(ocfg, tp, torch.from_numpy(mix), True)
-    for n in ocfg["source_names"]:
-        assert (outs[n].cpu() - oouts[n].detach()).abs().max().item() <= 5e-4, n
-    assert abs(loss.item() - oloss.item()) <= 5e-5 * abs(oloss.item())
-    _grad_check(sep, tp, [g.double() for g in ograds], tol=1e-2)
+    _out_check(outs, oouts, ocfg["source_names"], "deep_l16_f48 (fp32 oracle)")
+    _loss_check(loss.item(), oloss.item(), "deep_l16_f48 (fp32 oracle)")
+    _grad_check(sep, tp, ograds, tol=5e-3, tag="deep_l16_f48 (fp32 oracle)")
 
 
 @pytest.mark.parametrize("name", ["full_multi_small", "baseline_small"])
@@ -546,8 +584,8 @@ def test_autotuned_plan_keeps_parity(lib, name):
     tp = wt.params_to_torch(params, torch.float64, requires_grad=True)
     oloss, ograds = wt.train_step(ocfg, tp, torch.tensor(mix, dtype=torch.float64),
                                   {k: torch.tensor(v, dtype=torch.float64) for k, v in targets.items()})
-    assert abs(loss.item() - oloss.item()) <= 1e-5 * max(abs(oloss.item()), 1e-3)
-    _grad_check(sep, tp, ograds)
+    _loss_check(loss.item(), oloss.item(), "autotuned_" + name)
+    _grad_check(sep, tp, ograds, tag="autotuned_" + name)
     sep.get_output(dmix, True)
     l2 = sep.loss_and_gradients(tg)
     assert torch.equal(l2, loss) and torch.equal(sep.grads, g1)
@@ -567,7 +605,46 @@ def test_autotuned_full_size_m1_context(lib):
     sep.get_output(torch.from_numpy(mix).cuda(), True)
     loss = sep.loss_and_gradients(tg)
     torch.cuda.synchronize()
-    tp = wt.params_to_torch(params, torch.float32, requires_grad=True)
-    oloss, ograds = wt.train_step(ocfg, tp, torch.from_numpy(mix), tg)
-    assert abs(loss.item() - oloss.item()) <= 2e-5 * abs(oloss.item())
-    _grad_check(sep, tp, [g.double() for g in ograds], tol=5e-3)
+    oloss, ograds, oouts, tp = _oracle64(ocfg, params, mix, targets)
+    _loss_check(loss.item(), oloss, "autotuned_M1_context_full_B2")
+    _grad_check(sep, tp, ograds, tag="autotuned_M1_context_full_B2")
+
+
+def test_benchmarked_configuration_b16_tuned_vs_oracle(lib):
+    """EXACTLY what bench.py times -- BASELINE.json configs[1]: M1 with context, batch 16,
+    147443 -> 16389 samples, the Trainer's seed-1337 weights, the synthetic_source(seed 1337) batch
+    and the tilings bench.py runs (the pinned table profiles/round2_tune_table.txt through
+    WUN_TUNE_CACHE when it matches this build, a fresh wun_plan_tune otherwise) -- compared element
+    by element with the FLOAT64 oracle: outputs, loss and all 54 gradient tensors of the whole batch
+    (the oracle runs one excerpt at a time and averages: the loss is a mean over excerpts)."""
+    from wave_u_net_amd.training import Trainer, synthetic_source
+    cfg = wun.get_config("m1_context")
+    table = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "round2_tune_table.txt")
+    old = os.environ.get("WUN_TUNE_CACHE")
+    if os.path.exists(table):
+        os.environ["WUN_TUNE_CACHE"] = table
+    try:
+        tr = Trainer(cfg, batch_size=16)
+        assert (tr.t_in, tr.t_out) == (147443, 16389)
+        mix, targets = synthetic_source(cfg, 16, tr.t_in, tr.t_out, tr.device, seed=1337)()
+        tr.tune(mix, targets)
+    finally:
+        if old is None:
+            os.environ.pop("WUN_TUNE_CACHE", None)
+        else:
+            os.environ["WUN_TUNE_CACHE"] = old
+    sep = tr.sep
+    assert sep.tune_export().startswith("wun-tune 2 ")               # the plan really runs tuned tilings
+    outs = sep.get_output(mix, True)
+    loss = sep.loss_and_gradients(targets)
+    torch.cuda.synchronize()
+    names = cfg["source_names"]
+    var = sep.variables()
+    params = [(n, var[n].detach().cpu().numpy()) for n, _, _ in sep._active.tensors]
+    ocfg = shapes.finalize_config(dict(shapes.BASE_MODEL_CONFIG, context=True))
+    hmix = mix.cpu().numpy()
+    htg = {n: targets[k].cpu().numpy() for k, n in enumerate(names)}
+    oloss, ograds, oouts, tp = _oracle64(ocfg, params, hmix, htg)
+    _out_check(outs, oouts, names, "bench_config_B16_tuned")
+    _loss_check(loss.item(), oloss, "bench_config_B16_tuned")
+    _grad_check(sep, tp, ograds, tag="bench_config_B16_tuned")

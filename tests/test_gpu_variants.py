@@ -1,0 +1,323 @@
+"""Forced sweeps over EVERY tile variant of the two MFMA kernels (run with -m gpu on an MI355X).
+
+The autotuner picks tilings by speed alone, so each of them has to be correct on its own:
+  * conv_mfma_kernel: all variants of the table x split-K {1, 3} x the launch kinds the plan uses --
+    stride 1, the stride-2 de-interleaving loader, two virtual sources (crop_and_concat) with
+    accumulate + LeakyReLU mask, strided/offset output (transposed stride-2 conv, one phase) and the
+    fused two-phase transposed stride-2 conv -- through the C ABI test hooks
+    (wun_op_force_conv_variant; a choice the dispatcher would never make for a launch is REJECTED
+    by the library, not computed);
+  * wgrad_mfma_kernel<MTW, NW>: every instantiated geometry x split count {auto, 1, 3}
+    (wun_op_force_wgrad_variant).
+Every comparison is against a float64 torch-CPU reference of the same op; the last tests assert
+that no variant / geometry was left unexercised."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _observed import record
+
+pytestmark = pytest.mark.gpu
+
+from wave_u_net_amd import _lib                   # noqa: E402
+
+OP_TOL = 2e-5          # x max|ref|: fp32 MFMA chain over K*Cin <= 3000 products vs float64 (observed: see DESIGN.md)
+
+_RAN_CONV = {}         # variant -> set of launch kinds it was checked under
+_RAN_WGRAD = set()     # (mtw, nw)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return _lib.load()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _cuda(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).cuda()
+
+
+def _conv64(x, w, bias, stride, pad_left, t_out):
+    """float64 cross-correlation y[b][co][q] = bias + sum w[k][ci][co] x[b][ci][q*stride + k - pad_left]."""
+    K = w.shape[0]
+    xx = torch.as_tensor(x, dtype=torch.float64)
+    need = (t_out - 1) * stride + K - pad_left
+    xx = F.pad(xx, (pad_left, max(0, need - xx.shape[2])))
+    b = None if bias is None else torch.as_tensor(bias, dtype=torch.float64)
+    return F.conv1d(xx, torch.as_tensor(w, dtype=torch.float64).permute(2, 1, 0), b, stride=stride)[:, :, :t_out]
+
+
+def _t_out(T, K, stride, same):
+    return T if same else (T - K) // stride + 1
+
+
+# (B, Cin, Cout, K, T, same)  -- chosen so that, between them, every tile variant is a legal choice:
+# N = 48 admits 32/48/64/80-column tiles, N = 96 admits 96/128-column tiles, T >= 400 admits 384-row
+# tiles, the 1-/2-channel cases admit the 4-channel-chunk audio-input tiles, the B = 16 short cases
+# the batch-folded tiles.
+SWEEP_CASES = [
+    (2, 24, 48, 15, 800, False),
+    (2, 40, 96, 5, 420, True),
+    (2, 72, 80, 15, 430, False),
+    (2, 1, 24, 15, 900, False),
+    (2, 2, 24, 15, 300, False),
+    (16, 40, 48, 15, 39, False),
+    (16, 48, 96, 15, 95, False),
+    (6, 72, 48, 5, 77, True),
+    (16, 24, 64, 15, 151, False),
+]
+
+
+def _sweep(lib, kind, launch, check, ks_list=(1, 3)):
+    """Run `launch()` under every (variant, ksplit); rejected choices are skipped."""
+    nvar = lib.wun_op_num_conv_variants()
+    ran = 0
+    try:
+        for v in range(nvar):
+            for ks in ks_list:
+                lib.wun_op_force_conv_variant(v, ks)
+                rc = launch()
+                if rc != 0:
+                    continue
+                torch.cuda.synchronize()
+                check(v, ks)
+                _RAN_CONV.setdefault(v, set()).add(kind)
+                ran += 1
+    finally:
+        lib.wun_op_force_conv_variant(-1, 0)
+    return ran
+
+
+@pytest.mark.parametrize("case", SWEEP_CASES, ids=[str(c) for c in SWEEP_CASES])
+@pytest.mark.parametrize("stride", [1, 2])
+def test_conv_every_variant_forward(lib, case, stride):
+    B, Cin, Cout, K, T, same = case
+    if stride == 2 and same:
+        pytest.skip("the plan only uses the stride-2 loader with valid padding")
+    rng = np.random.default_rng(abs(hash((case, stride))) % (2 ** 31))
+    x = rng.uniform(-1, 1, (B, Cin, T)).astype(np.float32)
+    w = (rng.uniform(-1, 1, (K, Cin, Cout)) / np.sqrt(K * Cin)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, Cout).astype(np.float32)
+    pad = (K - 1) // 2 if same else 0
+    t_out = _t_out(T, K, stride, same)
+    ref = _conv64(x, w, b, stride, pad, t_out)
+    ref = torch.maximum(0.2 * ref, ref).numpy()
+    scale = max(1.0, np.abs(ref).max())
+    dx, dw, db_ = _cuda(x), _cuda(w), _cuda(b)
+    y = torch.empty((B, Cout, t_out), device="cuda")
+    worst = [0.0]
+
+    def launch():
+        y.fill_(float("nan"))
+        return lib.wun_op_conv1d(dx.data_ptr(), dw.data_ptr(), db_.data_ptr(), y.data_ptr(), B, Cin, Cout, K, T,
+                                 t_out, stride, pad, 1, _stream())
+
+    def check(v, ks):
+        got = y.cpu().numpy()
+        assert np.isfinite(got).all(), (v, ks)
+        err = np.abs(got - ref).max() / scale
+        worst[0] = max(worst[0], err)
+        assert err <= OP_TOL, (v, ks, err)
+
+    ran = _sweep(lib, "stride%d" % stride, launch, check)
+    assert ran >= 2
+    record("conv_every_variant_forward", "stride%d %s" % (stride, case), worst[0], OP_TOL)
+
+
+@pytest.mark.parametrize("case", SWEEP_CASES, ids=[str(c) for c in SWEEP_CASES])
+def test_conv_every_variant_two_sources_accumulate_mask(lib, case):
+    """The up-path launches: virtual concat of two sources; and the gradient-side epilogue: multiply
+    by the LeakyReLU derivative of the stored forward activation, accumulate into the destination."""
+    B, Cin, Cout, K, T, same = case
+    if Cin < 8:
+        pytest.skip("two sources need >= 8 input channels")
+    c0 = (Cin // 2 + 3) // 4 * 4
+    c1 = Cin - c0
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31) + 3)
+    x = rng.uniform(-1, 1, (B, Cin, T)).astype(np.float32)
+    w = (rng.uniform(-1, 1, (K, Cin, Cout)) / np.sqrt(K * Cin)).astype(np.float32)
+    pad = (K - 1) // 2 if same else 0
+    t_out = _t_out(T, K, 1, same)
+    fwd = rng.uniform(-1, 1, (B, Cout, t_out)).astype(np.float32)          # "forward activation" -> mask
+    base = rng.uniform(-1, 1, (B, Cout, t_out)).astype(np.float32)         # destination content before the launch
+    ref = _conv64(x, w, None, 1, pad, t_out).numpy() * np.where(fwd > 0, 1.0, 0.2) + base.astype(np.float64)
+    scale = max(1.0, np.abs(ref).max())
+    x0, x1 = _cuda(x[:, :c0]), _cuda(x[:, c0:])
+    dw, dmask, dbase = _cuda(w), _cuda(fwd), _cuda(base)
+    y = torch.empty((B, Cout, t_out), device="cuda")
+    worst = [0.0]
+
+    def launch():
+        y.copy_(dbase)
+        return lib.wun_op_conv1d_ex(x0.data_ptr(), c0, x1.data_ptr(), c1, dw.data_ptr(), None, y.data_ptr(),
+                                    dmask.data_ptr(), B, Cout, K, T, t_out, t_out, 1, pad, 0, 1, 1, 0, _stream())
+
+    def check(v, ks):
+        got = y.cpu().numpy()
+        assert np.isfinite(got).all(), (v, ks)
+        err = np.abs(got - ref).max() / scale
+        worst[0] = max(worst[0], err)
+        assert err <= OP_TOL, (v, ks, err)
+
+    ran = _sweep(lib, "two_source_accum_mask", launch, check)
+    assert ran >= 2
+    record("conv_every_variant_two_sources", str(case), worst[0], OP_TOL)
+
+
+@pytest.mark.parametrize("case", SWEEP_CASES[:3] + SWEEP_CASES[5:7], ids=[str(c) for c in SWEEP_CASES[:3] + SWEEP_CASES[5:7]])
+def test_conv_every_variant_strided_output(lib, case):
+    """One output phase of a transposed stride-2 conv / the same-padding decimation gradient: outputs
+    land at y[ooff + 2q] and accumulate there."""
+    B, Cin, Cout, K, T, same = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31) + 5)
+    x = rng.uniform(-1, 1, (B, Cin, T)).astype(np.float32)
+    w = (rng.uniform(-1, 1, (K, Cin, Cout)) / np.sqrt(K * Cin)).astype(np.float32)
+    pad = (K - 1) // 2 if same else 0
+    t_out = _t_out(T, K, 1, same)
+    t_y = 2 * t_out + 1
+    base = rng.uniform(-1, 1, (B, Cout, t_y)).astype(np.float32)
+    ref = base.astype(np.float64).copy()
+    ref[:, :, 1:1 + 2 * t_out:2] += _conv64(x, w, None, 1, pad, t_out).numpy()
+    scale = max(1.0, np.abs(ref).max())
+    dx, dw, dbase = _cuda(x), _cuda(w), _cuda(base)
+    y = torch.empty((B, Cout, t_y), device="cuda")
+    worst = [0.0]
+
+    def launch():
+        y.copy_(dbase)
+        return lib.wun_op_conv1d_ex(dx.data_ptr(), Cin, None, 0, dw.data_ptr(), None, y.data_ptr(), None, B, Cout, K,
+                                    T, t_out, t_y, 1, pad, 0, 1, 2, 1, _stream())
+
+    def check(v, ks):
+        got = y.cpu().numpy()
+        assert np.isfinite(got).all(), (v, ks)
+        err = np.abs(got - ref).max() / scale
+        worst[0] = max(worst[0], err)
+        assert err <= OP_TOL, (v, ks, err)
+
+    ran = _sweep(lib, "strided_output", launch, check)
+    assert ran >= 2
+    record("conv_every_variant_strided_output", str(case), worst[0], OP_TOL)
+
+
+PHASE2_CASES = [
+    # (B, Cin, Cout, K, T_in): input gradient of a stride-2 valid conv; Cin (the GEMM N) decides which
+    # fused two-phase tiles (32/64/96 columns = 16/32/48 channels x 2 phases) are legal
+    (2, 48, 72, 15, 1201),
+    (2, 24, 48, 15, 1400),
+    (2, 32, 40, 15, 1100),
+    (2, 96, 24, 7, 1000),
+]
+
+
+@pytest.mark.parametrize("case", PHASE2_CASES, ids=[str(c) for c in PHASE2_CASES])
+def test_conv_every_variant_fused_two_phase_dgrad(lib, case):
+    B, Cin, Cout, K, T = case
+    t_out = (T - K) // 2 + 1
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31) + 9)
+    w = (rng.uniform(-1, 1, (K, Cin, Cout)) / np.sqrt(K * Cin)).astype(np.float32)
+    dz = rng.uniform(-1, 1, (B, Cout, t_out)).astype(np.float32)
+    xt = torch.zeros((B, Cin, T), dtype=torch.float64, requires_grad=True)
+    yy = F.conv1d(xt, torch.tensor(w, dtype=torch.float64).permute(2, 1, 0), None, stride=2)
+    (yy * torch.tensor(dz, dtype=torch.float64)).sum().backward()
+    ref = xt.grad.numpy()
+    scale = max(1.0, np.abs(ref).max())
+    dw, dzg = _cuda(w), _cuda(dz)
+    wts = torch.empty(2 * K * Cin * Cout + 64, device="cuda")
+    gdx = torch.empty((B, Cin, T), device="cuda")
+    worst = [0.0]
+
+    def launch():
+        gdx.fill_(float("nan"))
+        return lib.wun_op_conv1d_dgrad(dzg.data_ptr(), dw.data_ptr(), gdx.data_ptr(), wts.data_ptr(), B, Cin, Cout, K,
+                                       T, t_out, 2, 0, _stream())
+
+    def check(v, ks):
+        got = gdx.cpu().numpy()
+        assert np.isfinite(got).all(), v
+        err = np.abs(got - ref).max() / scale
+        worst[0] = max(worst[0], err)
+        assert err <= OP_TOL, (v, err)
+
+    ran = _sweep(lib, "fused_two_phase", launch, check, ks_list=(1,))
+    assert ran >= 2
+    record("conv_every_variant_fused_two_phase", str(case), worst[0], OP_TOL)
+
+
+def test_every_conv_variant_was_exercised(lib):
+    nvar = lib.wun_op_num_conv_variants()
+    missing = [v for v in range(nvar) if v not in _RAN_CONV]
+    assert not missing, "conv tile variants never checked: %s" % missing
+    kinds = set().union(*_RAN_CONV.values())
+    assert kinds == {"stride1", "stride2", "two_source_accum_mask", "strided_output", "fused_two_phase"}, kinds
+    # every variant that can serve the fused two-phase launch (one wave column, even number of column
+    # tiles, 8-channel chunks, not batch-folded) was checked there
+    fused = sorted(v for v, k in _RAN_CONV.items() if "fused_two_phase" in k)
+    assert len(fused) >= 10, fused
+    print("[parity] conv variants x kinds:", {v: sorted(k) for v, k in sorted(_RAN_CONV.items())})
+
+
+WGRAD_CASES = [
+    # (B, Cin, Cout, K, T, stride, pad_left, same)
+    (2, 24, 48, 15, 700, 1, 0, False),
+    (2, 24, 80, 15, 701, 2, 0, False),
+    (2, 40, 24, 5, 300, 1, 2, True),
+    (16, 48, 56, 15, 95, 2, 0, False),
+    (3, 64, 72, 15, 23, 1, 0, False),
+]
+WGRAD_GEOMS = [(m, n) for m in (1, 2, 4) for n in (1, 2, 3, 4, 5)] + [(6, 1), (6, 2), (6, 3)]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=[str(c) for c in WGRAD_CASES])
+def test_wgrad_every_geometry_and_split(lib, case):
+    B, Cin, Cout, K, T, stride, pad, same = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31) + 11)
+    x = rng.uniform(-1, 1, (B, Cin, T)).astype(np.float32)
+    t_out = _t_out(T, K, stride, same)
+    dz = rng.uniform(-1, 1, (B, Cout, t_out)).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64)
+    wtn = torch.zeros((K, Cin, Cout), dtype=torch.float64, requires_grad=True)
+    need = (t_out - 1) * stride + K - pad
+    xp = F.pad(xt, (pad, max(0, need - T)))
+    y = F.conv1d(xp, wtn.permute(2, 1, 0), None, stride=stride)[:, :, :t_out]
+    (y * torch.tensor(dz, dtype=torch.float64)).sum().backward()
+    ref_dw = wtn.grad.numpy()
+    ref_db = dz.astype(np.float64).sum(axis=(0, 2))
+    sw, sb = max(1.0, np.abs(ref_dw).max()), max(1.0, np.abs(ref_db).max())
+    dxg, dzg = _cuda(x), _cuda(dz)
+    ran, worst = 0, 0.0
+    try:
+        for mtw, nw in WGRAD_GEOMS:
+            for ns in (0, 1, 3):
+                lib.wun_op_force_wgrad_variant(mtw, nw, ns)
+                scr = torch.empty(int(lib.wun_op_conv1d_wgrad_scratch(B, Cin, Cout, K, t_out)), device="cuda")
+                gdw = torch.full((K, Cin, Cout), float("nan"), device="cuda")
+                gdb = torch.full((Cout,), float("nan"), device="cuda")
+                rc = lib.wun_op_conv1d_wgrad(dxg.data_ptr(), dzg.data_ptr(), gdw.data_ptr(), gdb.data_ptr(),
+                                             scr.data_ptr(), B, Cin, Cout, K, T, t_out, stride, pad, _stream())
+                if rc == -2:
+                    continue               # geometry not available for this shape: refused, not miscomputed
+                _lib.check(rc)
+                torch.cuda.synchronize()
+                ew = np.abs(gdw.cpu().numpy() - ref_dw).max() / sw
+                eb = np.abs(gdb.cpu().numpy() - ref_db).max() / sb
+                assert ew <= OP_TOL and eb <= OP_TOL, (mtw, nw, ns, ew, eb)
+                worst = max(worst, ew, eb)
+                _RAN_WGRAD.add((mtw, nw))
+                ran += 1
+    finally:
+        lib.wun_op_force_wgrad_variant(0, 0, 0)
+    assert ran >= 6
+    record("wgrad_every_geometry_and_split", str(case), worst, OP_TOL)
+
+
+def test_every_wgrad_geometry_was_exercised(lib):
+    missing = [g for g in WGRAD_GEOMS if g not in _RAN_WGRAD]
+    assert not missing, "wgrad_mfma_kernel<MTW, NW> instantiations never checked: %s" % missing

@@ -64,6 +64,15 @@ def test_device_snippet_source_contract():
         assert torch.allclose(mix[:, pad:t_in - pad], targets.sum(0), atol=1e-6)                # mix = sum of amplified sources
         mixes.append(mix.cpu().numpy())
     assert not np.array_equal(mixes[0], mixes[1])
+    # same seed => the host pipeline's batches, bit for bit (both consume datasets.snippet_descriptors)
+    host = datasets.get_dataset(dict(cfg, batch_size=4), [4, t_in, 2], [4, t_out, 2], "train", tracks, seed=1)
+    src_b = datasets.DeviceSnippetSource(cfg, tracks, t_in, t_out, 4, "cuda:0", seed=1)
+    for _ in range(3):
+        hb = next(host)
+        mix, targets = src_b()
+        assert np.array_equal(mix.cpu().numpy(), hb["mix"])
+        for si, name in enumerate(cfg["source_names"]):
+            assert np.array_equal(targets[si].cpu().numpy(), hb[name]), name
     # without augmentation a snippet is a window of the stored (padded) mix
     cfg2 = dict(cfg, augmentation=False)
     src2 = datasets.DeviceSnippetSource(cfg2, tracks[:1], t_in, t_out, 2, "cuda:0", seed=2)

@@ -153,34 +153,33 @@ def crop_sample(sample, crop_frames):
     return {k: (v[crop_frames:-crop_frames, :] if (k != "mix" and crop_frames > 0) else v) for k, v in sample.items()}
 
 
-def get_dataset(model_config, input_shape, output_shape, partition, tracks, seed=1337):
-    """Generator of batches {source..., "mix"}: mix [B, Tin, C], sources [B, Tout, C]
-    (Datasets.get_dataset, Datasets.py:113-218, minus the TFRecord cache).  `tracks` is the list of
-    track dicts of this partition.  Train: endless, shuffled; otherwise one pass in order."""
-    input_frames, output_frames = int(input_shape[1]), int(output_shape[1])
-    assert (input_frames - output_frames) % 2 == 0
-    pad = (input_frames - output_frames) // 2
-    keys = list(model_config["source_names"]) + ["mix"]
-    batch_size = int(model_config["batch_size"])
-    rng = np.random.default_rng(seed)
-    padded = [pad_track(t, pad) for t in tracks]
+def snippet_descriptors(model_config, lengths, input_frames, output_frames, partition, rng):
+    """The reference's snippet stream (Datasets.py:188-216) as DESCRIPTORS (track_index, start, gains):
+    which snippet of which padded track comes next and, for train + augmentation, the per-source
+    gains of Utils.random_amplify (float32 [S], else None).  `lengths` are the padded track lengths.
+      train     : endless; per pass the tracks in shuffled order (:195), num_snippets_per_track
+                  uniform start positions each (:16-20,201-202), then the shuffle buffer of
+                  cache_size elements (:211-213)
+      otherwise : one pass, tracks in order, every hop of output_frames (:22-27,203-204)
+    Both producers below (host numpy batches, on-GPU gather) consume this one stream, so they
+    deliver identical batches for the same seed."""
     train = partition == "train"
+    S = len(model_config["source_names"])
+    n_tracks = len(lengths)
 
-    def snippets():
+    def raw():
         while True:
-            order = rng.permutation(len(padded)) if train else np.arange(len(padded))   # files are shuffled (:195)
+            order = rng.permutation(n_tracks) if train else np.arange(n_tracks)
             for ti in order:
-                tr = padded[ti]
-                length = tr["mix"].shape[0]
                 if train:
-                    pos = random_positions(length, input_frames, int(model_config["num_snippets_per_track"]), rng)
+                    pos = random_positions(lengths[ti], input_frames, int(model_config["num_snippets_per_track"]), rng)
                 else:
-                    pos = all_positions(length, input_frames, output_frames)
+                    pos = all_positions(lengths[ti], input_frames, output_frames)
                 for p in pos:
-                    s = {k: tr[k][p:p + input_frames, :] for k in keys}
+                    gains = None
                     if train and model_config["augmentation"]:
-                        s = random_amplify(s, rng)
-                    yield crop_sample(s, pad)
+                        gains = rng.uniform(0.7, 1.0, size=S).astype(np.float32)
+                    yield int(ti), int(p), gains
             if not train:
                 return
 
@@ -193,14 +192,43 @@ def get_dataset(model_config, input_shape, output_shape, partition, tracks, seed
             i = int(rng.integers(0, buffer_size))
             out, buf[i] = buf[i], s
             yield out
-        rng.shuffle(buf)
+        rng.shuffle(buf)                 # (finite streams only; the train stream repeats forever)
         for s in buf:
             yield s
 
-    stream = shuffled(snippets(), int(model_config["cache_size"])) if train else snippets()
+    return shuffled(raw(), int(model_config["cache_size"])) if train else raw()
+
+
+def materialize(track, keys, source_names, start, input_frames, gains, crop_frames):
+    """One snippet {key: [T, C]} from a padded track: cut (Datasets.py:29-34), amplify + re-sum the mix
+    (Utils.py:26-36, when gains are given), centre-crop the targets (Utils.py:38-42)."""
+    s = {k: track[k][start:start + input_frames, :] for k in keys}
+    if gains is not None:
+        amp = {k: np.float32(g) * s[k] for k, g in zip(source_names, gains)}
+        mix = amp[source_names[0]]
+        for k in source_names[1:]:
+            mix = mix + amp[k]
+        amp["mix"] = mix
+        s = amp
+    return crop_sample(s, crop_frames)
+
+
+def get_dataset(model_config, input_shape, output_shape, partition, tracks, seed=1337, rng=None):
+    """Generator of batches {source..., "mix"}: mix [B, Tin, C], sources [B, Tout, C]
+    (Datasets.get_dataset, Datasets.py:113-218, minus the TFRecord cache).  `tracks` is the list of
+    track dicts of this partition.  Train: endless, shuffled; otherwise one pass in order."""
+    input_frames, output_frames = int(input_shape[1]), int(output_shape[1])
+    assert (input_frames - output_frames) % 2 == 0
+    pad = (input_frames - output_frames) // 2
+    names = list(model_config["source_names"])
+    keys = names + ["mix"]
+    batch_size = int(model_config["batch_size"])
+    rng = rng if rng is not None else np.random.default_rng(seed)
+    padded = [pad_track(t, pad) for t in tracks]
+    lengths = [t["mix"].shape[0] for t in padded]
     batch = []
-    for s in stream:
-        batch.append(s)
+    for ti, pos, gains in snippet_descriptors(model_config, lengths, input_frames, output_frames, partition, rng):
+        batch.append(materialize(padded[ti], keys, names, pos, input_frames, gains, pad))
         if len(batch) == batch_size:
             yield {k: np.stack([b[k] for b in batch]) for k in keys}
             batch = []
@@ -218,12 +246,15 @@ def batch_to_device(batch, model_config, device):
 class DeviceSnippetSource(object):
     """Training batches produced on the GPU from tracks resident in HBM.
 
-    Same distribution as the reference's train pipeline (uniform snippet positions within a track,
-    equal number of snippets per track, shuffled; per-source gain U(0.7,1.0) and mix = sum when
-    augmentation is on; centre-cropped targets), drawn directly per batch instead of through a
-    shuffle buffer.  Calling the object returns (mix [B,Tin,C], targets [S,B,Tout,C])."""
+    The reference's train pipeline exactly (per pass: shuffled tracks, num_snippets_per_track uniform
+    positions per track, per-source gain U(0.7,1.0) and mix = sum when augmentation is on, shuffle
+    buffer of cache_size snippets, centre-cropped targets): the snippet stream is the same
+    snippet_descriptors() sequence the host pipeline consumes -- only (track, start, gains) triples
+    move through the shuffle buffer on the host, a few bytes per snippet -- and a batch is ONE
+    gather + gain + sum + crop on the GPU.  For equal seeds the batches are bit-identical to
+    get_dataset(..., "train", ...).  Calling the object returns (mix [B,Tin,C], targets [S,B,Tout,C])."""
 
-    def __init__(self, model_config, tracks, input_frames, output_frames, batch_size, device, seed=1337):
+    def __init__(self, model_config, tracks, input_frames, output_frames, batch_size, device, seed=1337, rng=None):
         import torch
         self.cfg = model_config
         self.names = list(model_config["source_names"])
@@ -231,7 +262,6 @@ class DeviceSnippetSource(object):
         self.pad = (self.t_in - self.t_out) // 2
         self.batch = int(batch_size)
         self.device = torch.device(device)
-        self.gen = torch.Generator(device=self.device).manual_seed(seed)
         starts, lens, cat = [], [], {k: [] for k in self.names + ["mix"]}
         off = 0
         for t in tracks:
@@ -242,23 +272,25 @@ class DeviceSnippetSource(object):
             starts.append(off); lens.append(n); off += n
             for k in cat:
                 cat[k].append(p[k])
-        self.track_start = torch.tensor(starts, dtype=torch.int64, device=self.device)
-        self.track_len = torch.tensor(lens, dtype=torch.int64, device=self.device)
+        self.track_start = np.asarray(starts, dtype=np.int64)
         self.data = {k: torch.from_numpy(np.concatenate(v)).to(self.device) for k, v in cat.items()}
         self.frame = torch.arange(self.t_in, device=self.device, dtype=torch.int64)
+        self.stream = snippet_descriptors(model_config, lens, self.t_in, self.t_out, "train",
+                                          rng if rng is not None else np.random.default_rng(seed))
 
     def __call__(self):
         import torch
-        B = self.batch
-        ti = torch.randint(0, self.track_start.numel(), (B,), generator=self.gen, device=self.device)
-        span = (self.track_len[ti] - self.t_in).to(torch.float64)
-        pos = (torch.rand((B,), generator=self.gen, device=self.device, dtype=torch.float64) * span).to(torch.int64)
-        idx = (self.track_start[ti] + pos)[:, None] + self.frame[None, :]                  # [B, Tin]
+        B, S = self.batch, len(self.names)
+        desc = [next(self.stream) for _ in range(B)]
+        base = torch.from_numpy(np.asarray([self.track_start[ti] + pos for ti, pos, _ in desc], dtype=np.int64))
+        idx = base.to(self.device)[:, None] + self.frame[None, :]                          # [B, Tin]
         srcs = torch.stack([self.data[k][idx] for k in self.names])                        # [S, B, Tin, C]
-        if self.cfg["augmentation"]:
-            gain = 0.7 + 0.3 * torch.rand((len(self.names), B, 1, 1), generator=self.gen, device=self.device)
-            srcs = srcs * gain
-            mix = srcs.sum(0)
+        if desc[0][2] is not None:
+            gain = torch.from_numpy(np.stack([g for _, _, g in desc], axis=1)).to(self.device)   # [S, B]
+            srcs = srcs * gain[:, :, None, None]
+            mix = srcs[0]
+            for s in range(1, S):                       # same summation order as the host pipeline
+                mix = mix + srcs[s]
         else:
             mix = self.data["mix"][idx]
         targets = srcs[:, :, self.pad:self.t_in - self.pad, :] if self.pad > 0 else srcs
