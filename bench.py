@@ -10,6 +10,13 @@ One "step" = one `sess.run([separator_solver, ...])` of /root/reference/Training
 get_output, MSE loss, full backward, TF-Adam update.  Rank 0 prints ONE JSON line.
 `value` = output samples/s of the whole job (N * B * Tout * K / max-over-ranks time);
 the input-sample rate (N * B * Tin) is reported in `config` for reference.
+
+Tilings: the per-launch tile table is read from profiles/round2_tune_table.txt (override with
+WUN_TUNE_CACHE) when it matches this plan and library build, so the timed launches are the ones the
+committed rocprofv3 / PMC profiles describe; otherwise rank 0 autotunes (untimed) and broadcasts.
+Extra objects in the line: `roofline` (kernel FAMILY conv_mfma_kernel, HIP events on the launch
+stream), `parity` (step 0 of the timed inputs vs the fp32 oracle), `cpu_baseline` (that oracle timed
+on the host cores, full batch + a 1-thread figure).
 """
 import argparse
 import ctypes
@@ -55,55 +62,110 @@ def usable_cores():
     return max(1, n)
 
 
-def pmc_traffic(kernel_name):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/round1_pmc_traffic.json: FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE,
-    separate passes); PMC counters cannot be collected from inside this process."""
-    path = os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")
+PINNED_TUNE_TABLE = os.path.join(ROOT, "profiles", "round2_tune_table.txt")
+
+
+def family_of(kernel_name):
+    return kernel_name.split("<")[0]
+
+
+def pmc_traffic(family, table_text):
+    """HBM bytes per launch of the kernel family (FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE,
+    separate rocprofv3 --pmc passes, tools/profile_round.sh) from the committed PMC summary -- but ONLY
+    if that summary was collected with the very tuning table this run executes (its sha is stored
+    beside the numbers); PMC counters cannot be collected from inside this process.  Else None."""
+    import hashlib
+    path = os.path.join(ROOT, "profiles", "round2_pmc_traffic.json")
     try:
-        table = json.load(open(path))["kernels"]
+        doc = json.load(open(path))
     except Exception:
         return None
-    import re
-    m = re.match(r"conv_mfma_kernel<(\d+, \d+, \d+, \d+, \d+), (?:true|false)(?:, (true|false|fold))?>", kernel_name)
-    key = ("conv_mfma_kernel<%s%s>" % (m.group(1), ", fold" if m.group(2) in ("true", "fold") else "")) if m else kernel_name
-    ent = table.get(key)
-    return ent["hbm_bytes_per_launch"] if ent else None
+    if not table_text or doc.get("tune_table_sha256") != hashlib.sha256(table_text.encode()).hexdigest():
+        return None
+    tot_b = tot_n = 0.0
+    for name, ent in doc["kernels"].items():
+        if family_of(name) == family:
+            tot_b += ent["hbm_bytes_per_launch"] * ent["launches_profiled"]
+            tot_n += ent["launches_profiled"]
+    return tot_b / tot_n if tot_n else None
 
 
-def cpu_baseline(cfg_name, cfg_over, budget_s=20.0):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg_over, params, mix, targets, names, gpu, budget_s=45.0):
     """The oracle (torch-CPU fp32 restatement of the reference graph; TensorFlow 1.8 cannot be
-    installed) timed on this box's host cores on a bounded sample of the same workload."""
+    installed) on THE batch the GPU timed: forward + backward of every excerpt (one excerpt at a time,
+    all usable host cores) + one TF-Adam update = one step of /root/reference/Training.py:103-109 at
+    batch_size 16; plus a 1-thread figure from one excerpt.  Its loss and gradients are also the
+    checker of the `parity` object.  Bounded: stops adding excerpts after budget_s seconds and scales."""
     from oracle import shapes, waveunet_torch as wt       # checker / CPU baseline only
     ocfg = shapes.finalize_config(dict(shapes.BASE_MODEL_CONFIG, **cfg_over))
     cores = usable_cores()
-    log("cpu baseline: os.cpu_count=%s usable=%d torch default threads=%d" % (os.cpu_count(), cores, torch.get_num_threads()))
+    log("cpu baseline: os.cpu_count=%s usable=%d model=%s" % (os.cpu_count(), cores, cpu_model()))
     torch.set_num_threads(cores)
-    B = 1
-    i, o = shapes.get_padding(ocfg, [B, ocfg["num_frames"], 0])
-    mix, targets = wt.synthetic_batch(ocfg, B, i[1], o[1], seed=1337)
-    tp = wt.params_to_torch(wt.init_params(ocfg, 1337), torch.float32, requires_grad=True)
-    m = [torch.zeros_like(p) for _, p in tp]
-    v = [torch.zeros_like(p) for _, p in tp]
-    tmix = torch.from_numpy(mix)
-    ttg = {k: torch.from_numpy(x) for k, x in targets.items()}
-    t0 = time.time()
-    wt.train_step(ocfg, tp, tmix, ttg, m, v, 1, 1e-4)      # warm-up (also the fallback timing)
-    warm = time.time() - t0
-    log("cpu baseline: warm-up step %.2f s" % warm)
-    times = []
+    B = mix.shape[0]
+    named = [(n, p) for n, p in params]
+    # warm-up (allocator, thread pool) on one excerpt, untimed
+    wt.chunked_train_step(ocfg, named, mix[:1], {k: v[:1] for k, v in targets.items()}, chunk=1)
+    times, loss_sum, acc, done = [], 0.0, None, 0
     t_start = time.time()
-    while len(times) < 20 and (time.time() - t_start) + (times[-1] if times else warm) < budget_s:
-        t1 = time.time()
-        wt.train_step(ocfg, tp, tmix, ttg, m, v, len(times) + 2, 1e-4)
-        times.append(time.time() - t1)
-    dt = float(np.median(times)) if times else warm
-    log("cpu baseline: %d timed steps, median %.2f s" % (len(times), dt))
-    return {"value": B * o[1] / dt, "unit": "output samples/s", "cores": cores, "kind": "port",
-            "sample": "%d timed step(s) of batch %d (of 16) excerpt(s) %d->%d, torch-CPU fp32 oracle, "
-                      "fwd+bwd+Adam, %.2f s/step%s" % (len(times), B, i[1], o[1], dt,
-                                                       "" if times else " (warm-up step only)"),
-            "threads": torch.get_num_threads()}
+    for b in range(B):
+        if b >= 4 and (time.time() - t_start) > budget_s:
+            break
+        tl = []
+        l, g, _ = wt.chunked_train_step(ocfg, named, mix[b:b + 1], {k: v[b:b + 1] for k, v in targets.items()},
+                                        chunk=1, timings=tl)
+        times.append(tl[0]); loss_sum += l
+        acc = g if acc is None else [a + x for a, x in zip(acc, g)]
+        done += 1
+    per_ex = float(np.median(times))
+    # Adam on the arena (7 words / parameter)
+    pp = [torch.tensor(p) for _, p in named]
+    gg = [(a / done).float() for a in acc]
+    mm = [torch.zeros_like(p) for p in pp]
+    vv = [torch.zeros_like(p) for p in pp]
+    t1 = time.time()
+    wt.tf_adam_step(pp, gg, mm, vv, 1, 1e-4)
+    t_adam = time.time() - t1
+    step_s = per_ex * B + t_adam
+    # 1-thread figure: one excerpt
+    torch.set_num_threads(1)
+    tl = []
+    wt.chunked_train_step(ocfg, named, mix[:1], {k: v[:1] for k, v in targets.items()}, chunk=1, timings=tl)
+    torch.set_num_threads(cores)
+    step_1t = tl[0] * B + t_adam                        # (Adam as measured above: bandwidth-bound)
+    t_out = targets[names[0]].shape[1]
+    log("cpu baseline: %d/%d excerpts timed, %.3f s/excerpt (%d threads), %.2f s/excerpt (1 thread), Adam %.3f s" % (
+        done, B, per_ex, cores, tl[0], t_adam))
+    base = {"value": B * t_out / step_s, "unit": "output samples/s", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model(), "threads": cores, "s_per_step": step_s,
+            "value_1_thread": B * t_out / step_1t, "s_per_step_1_thread": step_1t,
+            "sample": "fwd+bwd of %d of the batch's %d excerpts (%d->%d samples each, one at a time, median %.3f s "
+                      "x %d) + one TF-Adam update (%.3f s), torch-CPU fp32 oracle, %d threads; 1-thread figure from one "
+                      "excerpt (%.2f s) x %d" % (done, B, mix.shape[1], t_out, per_ex, B, t_adam, cores, tl[0], B)}
+    parity = None
+    if gpu is not None and done == B:
+        ograds = [a / B for a in acc]
+        worst, worst_name = 0.0, ""
+        for (n, _), og, (off, size) in zip(named, ograds, gpu["slices"]):
+            gg_ = gpu["grads"][off:off + size].double().reshape(og.shape)
+            rel = (gg_ - og).abs().max().item() / max(og.abs().max().item(), 1e-30)
+            if rel > worst:
+                worst, worst_name = rel, n
+        parity = {"checker": "torch-CPU fp32 oracle (oracle/waveunet_torch.py), the step-0 batch of the timed run",
+                  "loss_gpu": gpu["loss"], "loss_oracle": loss_sum / B,
+                  "loss_rel_err": abs(gpu["loss"] - loss_sum / B) / max(abs(loss_sum / B), 1e-30),
+                  "max_rel_grad_err": worst, "worst_tensor": worst_name, "tensors_checked": len(named),
+                  "rel_err_definition": "max|g_gpu - g_oracle| / max|g_oracle| per gradient tensor, worst tensor"}
+    return base, parity
 
 
 def main():
@@ -113,20 +175,41 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="m1_context")
     ap.add_argument("--batch", type=int, default=16)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline (and the parity object)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--force-allreduce", action="store_true",
+                    help="world 1 only: run the bucketed, overlapped RCCL gradient all-reduce of the N>1 path anyway "
+                         "(1-rank group: the collective kernels run and contend for CUs, the data is unchanged)")
+    ap.add_argument("--bucket-mib", type=float, default=16.0)
     args = ap.parse_args()
 
     import wave_u_net_amd as wun
     from wave_u_net_amd import _lib
     from wave_u_net_amd.training import Trainer, synthetic_source
 
+    if args.config == "m1_context" and args.batch == 16 and "WUN_TUNE_CACHE" not in os.environ \
+            and os.path.exists(PINNED_TUNE_TABLE) and os.environ.get("WUN_NO_TUNE") is None:
+        os.environ["WUN_TUNE_CACHE"] = PINNED_TUNE_TABLE      # the tilings the committed profiles describe
+
+    if args.force_allreduce and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import socket
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+
     cfg = wun.get_config(args.config)
     log("building trainer")
-    tr = Trainer(cfg, batch_size=args.batch)
+    tr = Trainer(cfg, batch_size=args.batch, bucket_mib=args.bucket_mib)
     world = tr.world
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    forced = None
+    if args.force_allreduce and world == 1:
+        from wave_u_net_amd.parallel import OverlappedGradAllReducer
+        plan = tr.sep._active
+        forced = OverlappedGradAllReducer(plan.tensors, plan.info.arena_floats, args.bucket_mib, device=tr.device)
+        log("forced all-reduce: %d buckets of >= %.0f MiB on a 1-rank RCCL group" % (len(forced.buckets), args.bucket_mib))
     source = synthetic_source(cfg, tr.batch, tr.t_in, tr.t_out, tr.device, seed=1337 + tr.rank)
     mix, targets = source()
     log("data ready: mix %s targets %s" % (tuple(mix.shape), tuple(targets.shape)))
@@ -135,18 +218,42 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def step():
+        if forced is None:
+            return tr.step(mix, targets)
+        tr.sep.get_output(mix, True)
+        loss_ = tr.sep.loss_and_gradients(targets, *forced.begin())
+        forced.launch(tr.sep.grads, force=True)
+        forced.finish()
+        tr.sep.adam_step(tr.lr, grad_scale=1.0)
+        return loss_
+
     t_tune = time.time()
-    tr.tune(mix, targets)                      # one-off autotuning of the per-launch tilings (untimed)
-    log("autotune: %.2f s" % (time.time() - t_tune))
+    tr.tune(mix, targets)                      # pinned table, or one-off autotuning on rank 0 + broadcast (untimed)
+    table_text = getattr(tr, "tune_table", None)
+    pinned = bool(table_text) and os.path.exists(PINNED_TUNE_TABLE) and table_text == open(PINNED_TUNE_TABLE).read()
+    log("tilings: %s (%.2f s)" % ("pinned table profiles/round2_tune_table.txt" if pinned else
+                                 ("autotuned" if table_text else "heuristic (WUN_NO_TUNE)"), time.time() - t_tune))
+
+    # ---- step 0 of the timed inputs, kept for the parity object (no optimizer step: weights untouched) ----
+    gpu0 = None
+    if tr.rank == 0 and world == 1 and not args.no_cpu_baseline:
+        tr.sep.get_output(mix, True)
+        l0 = tr.sep.loss_and_gradients(targets)
+        torch.cuda.synchronize()
+        gpu0 = {"loss": float(l0.item()), "grads": tr.sep.grads.detach().cpu(),
+                "slices": [(off, int(np.prod(shp))) for _, off, shp in tr.sep._active.tensors],
+                "params": [(n, v.detach().cpu().numpy().copy()) for n, v in tr.sep.variables().items()]}
+
     for _ in range(args.warmup):
-        loss = tr.step(mix, targets)
+        loss = step()
     torch.cuda.synchronize()
     log("warm-up done")
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = tr.step(mix, targets)
+        loss = step()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -161,6 +268,7 @@ def main():
     info = tr.sep.plan_info()
     ms_per_step = 1e3 * elapsed / args.steps
     out_samples = world * tr.batch * tr.t_out
+    step_flops = info.fwd_flops + info.bwd_flops
     result = {
         "metric": "waveform samples/sec fwd+bwd, M1 12-level Wave-U-Net @1/2/4/8 GPU",
         "value": out_samples * args.steps / elapsed,
@@ -181,9 +289,12 @@ def main():
                    "input_frames": tr.t_in, "output_frames": tr.t_out,
                    "input_samples_per_s": world * tr.batch * tr.t_in * args.steps / elapsed,
                    "parallelism": "dp%d" % world, "final_loss": loss_val,
-                   "step_tflops_executed": (info.fwd_flops + info.bwd_flops) / 1e12,
+                   "tilings": "pinned:profiles/round2_tune_table.txt" if pinned else ("autotuned" if table_text else "heuristic"),
+                   "forced_allreduce": bool(forced), "bucket_mib": args.bucket_mib,
+                   "step_tflops_executed": step_flops / 1e12,
                    "step_tflops_reference_graph": 3.0 * info.fwd_flops_dense / 1e12,
-                   "achieved_tflops_executed": (info.fwd_flops + info.bwd_flops) / (ms_per_step * 1e9)},
+                   "achieved_tflops_executed": step_flops / (ms_per_step * 1e9),
+                   "step_frac_of_fp32_mfma_peak": step_flops / (ms_per_step * 1e9) / PEAK_FP32_MFMA_TFLOPS},
     }
 
     if not args.no_roofline:
@@ -194,7 +305,7 @@ def main():
         if tr.rank == 0:
             lib.wun_profile_begin()
         for _ in range(nprof):
-            tr.step(mix, targets)
+            step()
         torch.cuda.synchronize()
         if tr.rank == 0:
             buf = ctypes.create_string_buffer(1 << 20)
@@ -205,30 +316,46 @@ def main():
                     json.dump(prof["launches"], f)
             kernels = prof["kernels"]
             kernels.sort(key=lambda k: -k["ms"])
+            fam = {}
             for k in kernels:
-                log("  %-42s launches/step %5.1f  ms/step %8.3f  TFLOP/s %7.2f" % (
-                    k["name"], k["launches"] / nprof, k["ms"] / nprof,
-                    k["flops"] / max(k["ms"], 1e-9) / 1e9))
-            top = kernels[0]
+                f = fam.setdefault(family_of(k["name"]), {"ms": 0.0, "flops": 0.0, "launches": 0})
+                f["ms"] += k["ms"]; f["flops"] += k["flops"]; f["launches"] += k["launches"]
+                log("  %-46s launches/step %5.1f  ms/step %8.3f  TFLOP/s %7.2f" % (
+                    k["name"], k["launches"] / nprof, k["ms"] / nprof, k["flops"] / max(k["ms"], 1e-9) / 1e9))
+            fams = sorted(fam.items(), key=lambda kv: -kv[1]["ms"])
+            for name, f in fams:
+                log("  family %-38s launches/step %5.1f  ms/step %8.3f  TFLOP/s %7.2f" % (
+                    name, f["launches"] / nprof, f["ms"] / nprof, f["flops"] / max(f["ms"], 1e-9) / 1e9))
+            top_name, top = fams[0]
             avg_ms = top["ms"] / top["launches"]
-            achieved = top["flops"] / top["launches"] / (avg_ms * 1e-3) / 1e12
+            achieved = top["flops"] / (top["ms"] * 1e-3) / 1e12
             result["roofline"] = {
-                "bound": "mfma", "kernel": top["name"], "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(top["name"]),
+                "bound": "mfma", "kernel": top_name + " (all instantiations)", "achieved": achieved,
+                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                "traffic": pmc_traffic(top_name, table_text),
                 "avg_launch_ms": avg_ms, "launches_per_step": top["launches"] / nprof,
                 "flops_per_launch": top["flops"] / top["launches"],
+                "family_ms_per_step": {n: f["ms"] / nprof for n, f in fams},
+                "family_frac": {n: f["flops"] / (f["ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS for n, f in fams if f["flops"] > 0},
+                "family_launches_per_step": {n: f["launches"] / nprof for n, f in fams},
                 "kernel_ms_per_step": {k["name"]: k["ms"] / nprof for k in kernels},
                 "kernel_tflops": {k["name"]: k["flops"] / (k["ms"] * 1e-3) / 1e12 for k in kernels if k["ms"] > 0},
             }
 
-    if tr.rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args.config, wun.NAMED_CONFIGS[args.config])
-        result["config"]["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
+    if gpu0 is not None:
+        names = list(cfg["source_names"])
+        htg = {n: targets[i].cpu().numpy() for i, n in enumerate(names)}
+        base, parity = cpu_baseline(wun.NAMED_CONFIGS[args.config], gpu0["params"], mix.cpu().numpy(), htg, names, gpu0)
+        result["cpu_baseline"] = base
+        if parity is not None:
+            result["parity"] = parity
+        result["config"]["speedup_vs_cpu_baseline"] = result["value"] / base["value"]
 
     if tr.rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
-        dist.barrier()
+    if dist.is_initialized():
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
 
 

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Turn the per-kernel PMC aggregates written by tools/pmc_summarize.py on the GPU box into the
 committed profile artefacts.
-usage: pmc_report.py <pmc_FETCH_SIZE.json> <pmc_WRITE_SIZE.json> <pmc_mfma.json> <out_traffic.json> <out_mfma.txt> [note]"""
+usage: pmc_report.py <pmc_FETCH_SIZE.json> <pmc_WRITE_SIZE.json> <pmc_mfma.json> <out_traffic.json> <out_mfma.txt> [note] [tune_table.txt]
+
+With a tuning table given, its sha256 is stored in the traffic file: bench.py reports `roofline.traffic`
+only when it runs exactly that table (same launches as the PMC passes)."""
 import json
 import sys
 
@@ -9,6 +12,10 @@ import sys
 def main():
     fetch, write, mfma = (json.load(open(a)) for a in sys.argv[1:4])
     note = sys.argv[6] if len(sys.argv) > 6 else ""
+    table_sha = None
+    if len(sys.argv) > 7:
+        import hashlib
+        table_sha = hashlib.sha256(open(sys.argv[7]).read().encode()).hexdigest()
     kernels = {}
     for name, f in fetch.items():
         w = write.get(name)
@@ -23,7 +30,9 @@ def main():
     json.dump({"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes, single-stream "
                        "(profiling) mode, tuned plan loaded from the tuning table, last step only "
                        "(tools/pmc_summarize.py); FETCH_SIZE doubled per MI355X_MICROARCH.md; counters are KiB; "
-                       "WRITE_SIZE uncalibrated. " + note, "kernels": kernels}, open(sys.argv[4], "w"), indent=1)
+                       "WRITE_SIZE uncalibrated. " + note, "tune_table_sha256": table_sha,
+               "step_hbm_bytes": sum(k["hbm_bytes_per_launch"] * k["launches_profiled"] for k in kernels.values()),
+               "kernels": kernels}, open(sys.argv[4], "w"), indent=1)
     rows = []
     tot_busy = tot_act = 0.0
     for name, c in mfma.items():

@@ -6,8 +6,13 @@ set -u
 tag=${1:-round}
 R=$PWD
 mkdir -p gpurun_out
+# tilings: the committed pinned table if it matches this build (PINNED=1, default), else a fresh one
 export WUN_TUNE_CACHE=$R/gpurun_out/${tag}_tune_table.txt
-[ "${KEEP_TUNE:-0}" = 1 ] || rm -f $WUN_TUNE_CACHE
+if [ "${PINNED:-1}" = 1 ] && [ -f $R/profiles/round2_tune_table.txt ]; then
+    cp $R/profiles/round2_tune_table.txt $WUN_TUNE_CACHE
+else
+    [ "${KEEP_TUNE:-0}" = 1 ] || rm -f $WUN_TUNE_CACHE
+fi
 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_${tag}
@@ -30,4 +35,6 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_A
     -d /tmp/pmc_mfma -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
 python $R/tools/pmc_summarize.py $(find /tmp/pmc_mfma -name "*counter_collection.csv" | head -1) $R/gpurun_out/${tag}_pmc_mfma.json
 cd $R
+python tools/pmc_report.py gpurun_out/${tag}_pmc_FETCH_SIZE.json gpurun_out/${tag}_pmc_WRITE_SIZE.json gpurun_out/${tag}_pmc_mfma.json \
+    gpurun_out/${tag}_pmc_traffic.json gpurun_out/${tag}_pmc_mfma_util.txt "$tag" $WUN_TUNE_CACHE
 tail -1 gpurun_out/${tag}_bench.json | cut -c1-400
