@@ -1074,31 +1074,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a, int nMG
     // off + Tin <= pitch.  Every vector is loaded from an in-row clamped position; zero fill
     // (virtual time outside [0, Tin), q beyond the batch) is applied at the LDS write and only
     // for units that touch a boundary, so interior units stage with almost no VALU work.
-    // Unit-invariant per-vector state is computed once:
-    //   xro[i] = element offset of the vector's source row (relative to the batch base)
-    //   xpk[i] = (LDS float offset << 10) | c4, bit 31 = this thread stages vector i, bit 30 = src1
-    int xro[WUN_WG_XIT], xpk[WUN_WG_XIT];
-    int zro[ZIT], zpk[ZIT];
+    // Unit-invariant per-vector state is ONE packed register per vector (the accumulator-heavy
+    // geometries have no registers to spare; the few VALU ops that unpack it per unit are noise
+    // next to the unit's hundreds of MFMAs):
+    //   xpk[i] = bit 31: this thread stages vector i | row (8 bits) << 23 | c4 (7 bits) << 16 | LDS float offset (16 bits)
+    //   zpk[i] = same fields for the dz tile
+    int xpk[WUN_WG_XIT];
+    int zpk[ZIT];
 #pragma unroll
     for (int i = 0; i < WUN_WG_XIT; ++i) {
         const int f = tid + i * 256;
         const int row = (int)(((float)f + 0.5f) * inv_xw4);
         const int c4 = f - row * XW4;
         const bool rok = row < nCh;
-        const int c = cLo + (rok ? row : 0);
-        const bool s0 = c < a.C0;
-        xro[i] = s0 ? c * a.pitch0 : (c - a.C0) * a.pitch1;
         const int ldsoff = deint ? (row * 2) * XP + 2 * c4 : row * XP + 4 * c4;
-        xpk[i] = rok ? (int)(0x80000000u | (s0 ? 0u : 0x40000000u) | ((unsigned)ldsoff << 10) | (unsigned)c4) : c4;
+        xpk[i] = rok ? (int)(0x80000000u | ((unsigned)row << 23) | ((unsigned)c4 << 16) | (unsigned)ldsoff)
+                     : (int)((unsigned)c4 << 16);
     }
 #pragma unroll
     for (int i = 0; i < ZIT; ++i) {
         const int f = tid + i * 256;
         const int row = (int)(((float)f + 0.5f) * inv_tk4);
         const int c4 = f - row * TK4;
-        const int nn = ng * NG + row;
-        zro[i] = ((row < NG && nn < a.N) ? nn : 0) * a.dzpitch;
-        zpk[i] = row < NG ? (int)(0x80000000u | ((unsigned)(row * ZP + 4 * c4) << 10) | (unsigned)c4) : c4;
+        zpk[i] = row < NG ? (int)(0x80000000u | ((unsigned)row << 23) | ((unsigned)c4 << 16) | (unsigned)(row * ZP + 4 * c4))
+                          : (int)((unsigned)c4 << 16);
     }
 
     auto load_unit = [&](int u) {
@@ -1110,19 +1109,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a, int nMG
         const int e00 = (tb + a.off0) & ~3, e01 = (tb + a.off1) & ~3;   // uniform element shift per source
 #pragma unroll
         for (int i = 0; i < WUN_WG_XIT; ++i) {
-            const bool s1 = (xpk[i] & 0x40000000) != 0;
-            int e = (s1 ? e01 : e00) + ((xpk[i] & 1023) << 2);         // element index inside the row
+            int pk = xpk[i];
+            asm volatile("" : "+v"(pk));          // keep the unpacking inside the unit loop (no hoisted copies)
+            const int c = cLo + ((pk >> 23) & 255);                   // rows past nCh carry row 0
+            const bool s1 = c >= a.C0;
+            const int xro = s1 ? (c - a.C0) * a.pitch1 : c * a.pitch0; // element offset of the source row
+            int e = (s1 ? e01 : e00) + (((pk >> 16) & 127) << 2);      // element index inside the row
             const int emax = (s1 ? a.pitch1 : a.pitch0) - 4;
             e = e < 0 ? 0 : (e > emax ? emax : e);
-            xreg[i] = *reinterpret_cast<const f32x4*>((s1 ? base1 : base0) + xro[i] + e);
+            xreg[i] = *reinterpret_cast<const f32x4*>((s1 ? base1 : base0) + xro + e);
         }
         const float* zb = a.dz + (long long)b * a.dzbs;
         const int qmax = a.dzpitch - 4;
 #pragma unroll
         for (int i = 0; i < ZIT; ++i) {
-            int q = q0 + ((zpk[i] & 1023) << 2);
+            int pk = zpk[i];
+            asm volatile("" : "+v"(pk));
+            const int nn = ng * NG + ((pk >> 23) & 255);
+            const int zro = (pk < 0 && nn < a.N ? nn : 0) * a.dzpitch;
+            int q = q0 + (((pk >> 16) & 127) << 2);
             q = q > qmax ? qmax : q;
-            zreg[i] = *reinterpret_cast<const f32x4*>(zb + zro[i] + q);
+            zreg[i] = *reinterpret_cast<const f32x4*>(zb + zro + q);
         }
     };
     auto store_unit = [&](int u) {
@@ -1136,15 +1143,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a, int nMG
         const bool xedge = t00 < 0 || t00 + span > a.Tin || (a.C1 > 0 && (t01 < 0 || t01 + span > a.Tin));
 #pragma unroll
         for (int i = 0; i < WUN_WG_XIT; ++i) {
-            if (xpk[i] < 0) {
+            int pk = xpk[i];
+            asm volatile("" : "+v"(pk));
+            if (pk < 0) {
                 f32x4 v = xreg[i];
                 if (xedge) {
-                    const int t0 = ((xpk[i] & 0x40000000) ? t01 : t00) + ((xpk[i] & 1023) << 2);
+                    const bool s1 = cLo + ((pk >> 23) & 255) >= a.C0;
+                    const int t0 = (s1 ? t01 : t00) + (((pk >> 16) & 127) << 2);
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         if (t0 + k < 0 || t0 + k >= a.Tin) v[k] = 0.f;
                 }
-                float* dstp = Xs + ((xpk[i] >> 10) & 0xFFFFF);
+                float* dstp = Xs + (pk & 0xFFFF);
                 if (!deint) {
                     *reinterpret_cast<f32x4*>(dstp) = v;
                 } else {
@@ -1156,15 +1166,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a, int nMG
         const bool zedge = nq < TK;
 #pragma unroll
         for (int i = 0; i < ZIT; ++i) {
-            if (zpk[i] < 0) {
+            int pk = zpk[i];
+            asm volatile("" : "+v"(pk));
+            if (pk < 0) {
                 f32x4 v = zreg[i];
                 if (zedge) {
-                    const int c4x = (zpk[i] & 1023) << 2;
+                    const int c4x = ((pk >> 16) & 127) << 2;
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         if (c4x + k >= nq) v[k] = 0.f;
                 }
-                float* p = Zs + ((zpk[i] >> 10) & 0xFFFFF);
+                float* p = Zs + (pk & 0xFFFF);
                 *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
                 *reinterpret_cast<float2*>(p + 2) = make_float2(v[2], v[3]);
             }
