@@ -34,6 +34,11 @@ import torch         # noqa: E402
 import torch.distributed as dist   # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA = fp32 vector peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide: dense bf16 MFMA (the 5 PF headline figure includes 2:1 sparsity)
+
+
+def family_peak(family):
+    return PEAK_BF16_MFMA_TFLOPS if family.startswith("conv_bf16") else PEAK_FP32_MFMA_TFLOPS
 _T0 = time.time()
 
 
@@ -181,6 +186,9 @@ def main():
                     help="world 1 only: run the bucketed, overlapped RCCL gradient all-reduce of the N>1 path anyway "
                          "(1-rank group: the collective kernels run and contend for CUs, the data is unchanged)")
     ap.add_argument("--bucket-mib", type=float, default=16.0)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32 = the reference's arithmetic (headline); bf16 = the speed mode of BASELINE.json configs[2],[4]: "
+                         "conv / input-gradient MFMA operands in bf16, fp32 accumulate, fp32 HBM tensors / weight gradients / Adam")
     args = ap.parse_args()
 
     import wave_u_net_amd as wun
@@ -199,6 +207,9 @@ def main():
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
 
     cfg = wun.get_config(args.config)
+    if args.dtype == "bf16":
+        cfg["compute_dtype"] = "bf16"
+        os.environ.pop("WUN_TUNE_CACHE", None) if os.environ.get("WUN_TUNE_CACHE") == PINNED_TUNE_TABLE else None
     log("building trainer")
     tr = Trainer(cfg, batch_size=args.batch, bucket_mib=args.bucket_mib)
     world = tr.world
@@ -237,7 +248,7 @@ def main():
 
     # ---- step 0 of the timed inputs, kept for the parity object (no optimizer step: weights untouched) ----
     gpu0 = None
-    if tr.rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if tr.rank == 0 and world == 1 and not args.no_cpu_baseline and args.config in wun.NAMED_CONFIGS:
         tr.sep.get_output(mix, True)
         l0 = tr.sep.loss_and_gradients(targets)
         torch.cuda.synchronize()
@@ -276,7 +287,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if args.dtype == "f32" else "bf16 (conv/dgrad MFMA operands; fp32 accumulate, storage, wgrad, Adam)",
+        "data": "synthetic",
         "config": {"workload": ("BASELINE.json configs[1]: M1 (12 levels, 24 ch, 15/5 filters, mono) with context, "
                                 "fwd+bwd+Adam, batch %d/GPU, %d -> %d samples" % (tr.batch, tr.t_in, tr.t_out))
                                if args.config == "m1_context" else
@@ -331,12 +343,12 @@ def main():
             achieved = top["flops"] / (top["ms"] * 1e-3) / 1e12
             result["roofline"] = {
                 "bound": "mfma", "kernel": top_name + " (all instantiations)", "achieved": achieved,
-                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                "peak": family_peak(top_name), "unit": "TFLOP/s", "frac": achieved / family_peak(top_name),
                 "traffic": pmc_traffic(top_name, table_text),
                 "avg_launch_ms": avg_ms, "launches_per_step": top["launches"] / nprof,
                 "flops_per_launch": top["flops"] / top["launches"],
                 "family_ms_per_step": {n: f["ms"] / nprof for n, f in fams},
-                "family_frac": {n: f["flops"] / (f["ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS for n, f in fams if f["flops"] > 0},
+                "family_frac": {n: f["flops"] / (f["ms"] * 1e-3) / 1e12 / family_peak(n) for n, f in fams if f["flops"] > 0},
                 "family_launches_per_step": {n: f["launches"] / nprof for n, f in fams},
                 "kernel_ms_per_step": {k["name"]: k["ms"] / nprof for k in kernels},
                 "kernel_tflops": {k["name"]: k["flops"] / (k["ms"] * 1e-3) / 1e12 for k in kernels if k["ms"] > 0},

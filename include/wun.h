@@ -58,6 +58,10 @@ typedef struct wun_config {
     int32_t num_sources;        /* len(source_names)                                          */
     int32_t num_channels;       /* 1 if mono_downmix else 2                                   */
     int32_t output_activation;  /* 0 = "tanh", 1 = "linear"                                   */
+    int32_t compute_dtype;      /* 0 = exact fp32 (v_mfma_f32_16x16x4_f32; the reference's arithmetic), */
+                                /* 1 = bf16 speed mode: conv / input-gradient operands rounded to bf16  */
+                                /*     on v_mfma_f32_16x16x32_bf16, fp32 accumulate; weights, Adam state,*/
+                                /*     activations in HBM, weight gradients and the head stay fp32        */
 } wun_config;
 
 typedef struct wun_plan wun_plan;
@@ -198,6 +202,17 @@ int wun_op_num_conv_variants(void);
  * (0 = automatic).  Call wun_op_conv1d_wgrad_scratch AFTER forcing: the scratch size depends on it.
  * A geometry the kernel's staging cannot hold for the shape fails with WUN_ERR_UNSUPPORTED. */
 int wun_op_force_wgrad_variant(int mtw, int nw, int nsplit);
+
+/* The bf16 speed mode's conv as a single operator (wun_op_conv1d semantics, Cin >= 8, K <= 15): operands
+ * are rounded to bf16 (nearest-even), products accumulate in fp32.  scratch: device floats, at least
+ * wun_op_conv1d_bf16_scratch(cin, cout, k) (packed bf16 weight image).  Synchronises the stream. */
+int64_t wun_op_conv1d_bf16_scratch(int cin, int cout, int k);
+int wun_op_conv1d_bf16(const float* x, const float* w, const float* bias, float* y, float* scratch,
+                       int batch, int cin, int cout, int k, int t_in, int t_out, int stride, int pad_left,
+                       int lrelu, void* stream);
+
+/* Lane layout probe of v_mfma_f32_16x16x32_bf16: d[16][16] = bf16(a[16][32]) * bf16(b[32][16]) (row-major). */
+int wun_op_mfma_bf16_probe(const float* a, const float* b, float* d, void* stream);
 
 /* Lane layout probe of v_mfma_f32_16x16x4_f32: d[16][16] = a[16][4] * b[4][16] (row-major). */
 int wun_op_mfma_probe(const float* a, const float* b, float* d, void* stream);

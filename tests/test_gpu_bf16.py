@@ -1,0 +1,174 @@
+"""bf16-MFMA speed mode (wun_config.compute_dtype = 1; BASELINE.json configs[2], [4]) on an MI355X.
+
+What the mode changes: the operands of every conv / input-gradient MFMA (Cin >= 8) are rounded to bf16
+(nearest-even) and multiplied on v_mfma_f32_16x16x32_bf16 with fp32 accumulation; HBM tensors, master
+weights, Adam, the weight gradients, the 1-/2-channel input conv and the output head stay fp32.
+Checks: (1) the MFMA lane layout; (2) the bf16 conv operator against a float64 conv of the
+bf16-ROUNDED operands -- products of bf16 numbers are exact in fp32, so this holds to fp32
+accumulation error (OP_TOL), i.e. the kernel is exact up to the stated operand rounding; (3) whole
+training steps against the float64 oracle (un-rounded) within the mode's own, looser tolerances
+(BF16_*), stated below and logged like the fp32 ones."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import shapes, waveunet_torch as wt
+from oracle.golden_params import GOLDEN_CASES, golden_params
+from _observed import record
+
+pytestmark = pytest.mark.gpu
+
+import wave_u_net_amd as wun                      # noqa: E402
+from wave_u_net_amd import _lib                   # noqa: E402
+from wave_u_net_amd.separator import UnetAudioSeparator   # noqa: E402
+
+OP_TOL = 2e-5            # bf16 conv op vs float64 conv of the bf16-rounded operands, x max|ref|
+BF16_OUT_TOL = 2e-2      # network outputs vs the float64 oracle, absolute (outputs are O(1))
+BF16_LOSS_TOL = 2e-2     # relative
+BF16_GRAD_TOL = 6e-2     # x max|g| per gradient tensor
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return _lib.load()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _cuda(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).cuda()
+
+
+def _bf16_round(a):
+    return torch.as_tensor(a, dtype=torch.float32).to(torch.bfloat16).to(torch.float64).numpy()
+
+
+def test_bf16_mfma_lane_layout(lib):
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((16, 32)).astype(np.float32)
+    b = rng.standard_normal((32, 16)).astype(np.float32)
+    da, db = _cuda(a), _cuda(b)
+    dd = torch.zeros(16, 16, device="cuda")
+    _lib.check(lib.wun_op_mfma_bf16_probe(da.data_ptr(), db.data_ptr(), dd.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    ref = _bf16_round(a) @ _bf16_round(b)
+    assert np.abs(dd.cpu().numpy() - ref).max() < 1e-5 * max(1.0, np.abs(ref).max())
+
+
+BF16_CONV_CASES = [
+    # (B, Cin, Cout, K, T, stride, pad_left, same)
+    (2, 24, 48, 15, 700, 1, 0, False),
+    (2, 24, 48, 15, 701, 2, 0, False),
+    (16, 48, 72, 15, 1100, 2, 0, False),
+    (2, 72, 24, 5, 2500, 1, 0, False),
+    (2, 40, 24, 5, 300, 1, 2, True),
+    (2, 24, 48, 15, 512, 1, 7, True),
+    (3, 288, 312, 15, 23, 1, 0, False),
+    (2, 264, 288, 15, 59, 2, 0, False),
+    (2, 600, 288, 5, 17, 1, 0, False),
+    (2, 13, 12, 4, 90, 1, 1, True),
+    (2, 9, 8, 7, 91, 2, 0, False),
+    (16, 120, 144, 15, 2305, 2, 0, False),
+    (16, 168, 72, 5, 4105, 1, 0, False),
+    (1, 96, 120, 15, 260, 2, 0, False),
+]
+
+
+@pytest.mark.parametrize("case", BF16_CONV_CASES, ids=[str(c) for c in BF16_CONV_CASES])
+def test_op_conv1d_bf16_is_exact_up_to_operand_rounding(lib, case):
+    B, Cin, Cout, K, T, stride, pad, same = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    x = rng.uniform(-1, 1, (B, Cin, T)).astype(np.float32)
+    w = (rng.uniform(-1, 1, (K, Cin, Cout)) / np.sqrt(K * Cin)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, Cout).astype(np.float32)
+    t_out = T if same else (T - K) // stride + 1
+    need = (t_out - 1) * stride + K - pad
+    xx = F.pad(torch.tensor(_bf16_round(x)), (pad, max(0, need - T)))
+    ref = F.conv1d(xx, torch.tensor(_bf16_round(w)).permute(2, 1, 0), torch.tensor(b, dtype=torch.float64), stride=stride)[:, :, :t_out]
+    ref = torch.maximum(0.2 * ref, ref).numpy()
+    y = torch.full((B, Cout, t_out), float("nan"), device="cuda")
+    dx, dw, db_ = _cuda(x), _cuda(w), _cuda(b)
+    scr = torch.empty(int(lib.wun_op_conv1d_bf16_scratch(Cin, Cout, K)), device="cuda")
+    _lib.check(lib.wun_op_conv1d_bf16(dx.data_ptr(), dw.data_ptr(), db_.data_ptr(), y.data_ptr(), scr.data_ptr(), B, Cin,
+                                      Cout, K, T, t_out, stride, pad, 1, _stream()))
+    torch.cuda.synchronize()
+    got = y.cpu().numpy()
+    assert np.isfinite(got).all()
+    err = np.abs(got - ref).max() / max(1.0, np.abs(ref).max())
+    record("op_conv1d_bf16_vs_rounded_operands", str(case), err, OP_TOL)
+    assert err <= OP_TOL
+
+
+def _step(cfg_over, ocfg, params, B, frames, seed, tag, tune=False):
+    sep = UnetAudioSeparator(wun.get_config("baseline", compute_dtype="bf16", **cfg_over), device="cuda:0")
+    i, o = shapes.get_padding(ocfg, [B, frames, 0])
+    mix, targets = wt.synthetic_batch(ocfg, B, i[1], o[1], seed=seed)
+    sep._plan(B, i[1]); sep._active = sep._plans[(B, i[1])]
+    sep.load_variables(params)
+    dmix = torch.from_numpy(mix).cuda()
+    tg = {k: torch.from_numpy(v) for k, v in targets.items()}
+    if tune:
+        sep.tune(dmix, tg)
+    outs = sep.get_output(dmix, True)
+    loss = sep.loss_and_gradients(tg)
+    torch.cuda.synchronize()
+    oloss, ograds, oouts = wt.chunked_train_step(ocfg, params, mix, targets, dtype=torch.float64, chunk=1, want_outputs=True)
+    names = ocfg["source_names"]
+    eo = max((outs[n].cpu().double() - oouts[n]).abs().max().item() for n in names)
+    record("bf16_outputs_vs_float64_oracle", tag, eo, BF16_OUT_TOL)
+    el = abs(loss.item() - oloss) / max(abs(oloss), 1e-3)
+    record("bf16_loss_vs_float64_oracle", tag, el, BF16_LOSS_TOL)
+    g = sep.gradients()
+    worst = (0.0, "")
+    for (n, _), og in zip(params, ograds):
+        got = g[n].cpu().double()
+        assert torch.isfinite(got).all(), n
+        rel = (got - og).abs().max().item() / max(og.abs().max().item(), 1e-30)
+        if rel > worst[0]:
+            worst = (rel, n)
+    record("bf16_gradients_vs_float64_oracle", "%s (worst: %s)" % (tag, worst[1]), worst[0], BF16_GRAD_TOL)
+    assert eo <= BF16_OUT_TOL and el <= BF16_LOSS_TOL and worst[0] <= BF16_GRAD_TOL, (eo, el, worst)
+    return sep
+
+
+@pytest.mark.parametrize("name", ["baseline_small", "baseline_stereo_small", "full_small", "full_multi_small",
+                                  "learned_same_small", "odd_filters_small"])
+def test_bf16_train_step_small_configs(lib, name):
+    case = GOLDEN_CASES[name]
+    ocfg = shapes.finalize_config(dict(shapes.BASE_MODEL_CONFIG, **case["cfg"]))
+    _step(case["cfg"], ocfg, golden_params(ocfg, case["seed"]), 3, case["frames"], case["seed"] + 100, "bf16_" + name)
+
+
+def test_bf16_full_size_m4_baseline_stereo(lib):
+    """BASELINE.json configs[2]: M4 context + stereo + difference output at full size (147443 -> 16389), B = 2."""
+    over = dict(output_type="difference", context=True, mono_downmix=False)
+    ocfg = shapes.finalize_config(dict(shapes.BASE_MODEL_CONFIG, **over))
+    sep = _step(over, ocfg, golden_params(ocfg, 91), 2, 16384, 92, "bf16_M4_baseline_stereo_full_B2")
+    # bit-determinism is kept in the speed mode too
+    assert sep.plan_info().output_frames == 16389
+
+
+def test_bf16_mode_leaves_fp32_mode_alone(lib):
+    """The same separator class in the default mode is still the exact-fp32 path (no bf16 rounding)."""
+    case = GOLDEN_CASES["baseline_context_small"]
+    ocfg = shapes.finalize_config(dict(shapes.BASE_MODEL_CONFIG, **case["cfg"]))
+    params = golden_params(ocfg, case["seed"])
+    i, o = shapes.get_padding(ocfg, [2, case["frames"], 0])
+    mix, _ = wt.synthetic_batch(ocfg, 2, i[1], o[1], seed=5)
+    outs = {}
+    for dt in ("f32", "bf16"):
+        sep = UnetAudioSeparator(wun.get_config("baseline", compute_dtype=dt, **case["cfg"]), device="cuda:0")
+        sep._plan(2, i[1]); sep._active = sep._plans[(2, i[1])]
+        sep.load_variables(params)
+        outs[dt] = torch.stack(list(sep.get_output(torch.from_numpy(mix).cuda(), True).values())).cpu()
+    tp = wt.params_to_torch(params, torch.float64, requires_grad=False)
+    ref = torch.stack(list(wt.get_output(ocfg, tp, torch.tensor(mix, dtype=torch.float64), True).values()))
+    e32 = (outs["f32"].double() - ref).abs().max().item()
+    e16 = (outs["bf16"].double() - ref).abs().max().item()
+    assert e32 <= 5e-6 and e16 > 10 * e32 and e16 <= BF16_OUT_TOL, (e32, e16)

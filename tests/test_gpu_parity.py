@@ -22,10 +22,12 @@ from _observed import record
 
 pytestmark = pytest.mark.gpu
 
+# observed on MI355X (gpurun_out/parity_observed.json, round 2): ops <= 1.5e-6, outputs <= 4.8e-7,
+# loss <= 1.3e-7, gradients <= 7.1e-5 (the benchmarked B=16 configuration) -- tolerances ~7-13x that
 OP_TOL = 2e-5        # x max|ref|
-OUT_TOL = 5e-5       # absolute, outputs are O(1)
-LOSS_TOL = 1e-5      # relative
-GRAD_TOL = 1e-3      # x max|g| per tensor, vs the float64 oracle
+OUT_TOL = 5e-6       # absolute, outputs are O(1)
+LOSS_TOL = 2e-6      # relative
+GRAD_TOL = 5e-4      # x max|g| per tensor, vs the float64 oracle
 
 import wave_u_net_amd as wun                      # noqa: E402
 from wave_u_net_amd import _lib                   # noqa: E402
@@ -139,7 +141,7 @@ FOLD_CASES = [
     (16, 48, 96, 15, 95, 2, 0, False),      # stride 2, T_out 41
     (6, 72, 48, 5, 77, 1, 2, True),         # 'same' padding, T_out 77
     (16, 24, 64, 15, 151, 1, 0, False),     # T_out 137: two excerpts per 128-row tile
-    (3, 32, 128, 7, 19, 2, 0, False),       # T_out 7 < 9
+    (16, 32, 128, 7, 19, 2, 0, False),      # T_out 7 < 9
 ]
 
 
@@ -286,7 +288,7 @@ def _grad_check(sep, tp, ograds, tol=GRAD_TOL, tag="?"):
         og = og.double()
         scale = max(og.abs().max().item(), 1e-30)
         err = (got - og).abs().max().item()
-        worst.append((max(0.0, err - 1e-7) / scale, n, err, scale))
+        worst.append((err / scale, n, err, scale))
         assert torch.isfinite(got).all(), n
     worst.sort(reverse=True)
     record("gradients_vs_float64_oracle", "%s (worst: %s)" % (tag, worst[0][1]), worst[0][0], tol)

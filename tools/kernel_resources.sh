@@ -5,7 +5,7 @@ set -e
 R=$(cd $(dirname $0)/.. && pwd)
 T=$(mktemp -d)
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 --cuda-device-only -Wno-unused-function "$@" \
-    -c $R/wave-u-net_amd/csrc/wun_kernels.hip -o $T/k.co
+    -c $R/wave-u-net_amd/csrc/${SRC:-wun_kernels.hip} -o $T/k.co
 /opt/rocm/lib/llvm/bin/clang-offload-bundler --unbundle --type=o --input=$T/k.co \
     --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=$T/k.elf
 /opt/rocm/lib/llvm/bin/llvm-readelf --notes $T/k.elf > $T/notes.txt

@@ -11,7 +11,7 @@ class WunConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "num_layers", "num_initial_filters", "filter_size", "merge_filter_size",
         "input_filter_size", "output_filter_size", "upsampling", "output_type", "context",
-        "num_sources", "num_channels", "output_activation")]
+        "num_sources", "num_channels", "output_activation", "compute_dtype")]
 
 
 class WunPlanInfo(C.Structure):
@@ -48,6 +48,9 @@ _SIGS = {
     "wun_op_conv1d_wgrad": (C.c_int, [_P, _P, _P, _P, _P] + [C.c_int] * 8 + [_P]),
     "wun_op_conv1d_dgrad": (C.c_int, [_P, _P, _P, _P] + [C.c_int] * 8 + [_P]),
     "wun_op_mfma_probe": (C.c_int, [_P, _P, _P, _P]),
+    "wun_op_mfma_bf16_probe": (C.c_int, [_P, _P, _P, _P]),
+    "wun_op_conv1d_bf16_scratch": (C.c_int64, [C.c_int] * 3),
+    "wun_op_conv1d_bf16": (C.c_int, [_P, _P, _P, _P, _P] + [C.c_int] * 9 + [_P]),
     "wun_op_force_conv_variant": (C.c_int, [C.c_int, C.c_int]),
     "wun_op_num_conv_variants": (C.c_int, []),
     "wun_op_force_wgrad_variant": (C.c_int, [C.c_int, C.c_int, C.c_int]),

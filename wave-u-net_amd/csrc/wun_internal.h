@@ -51,6 +51,7 @@ struct ConvArgs {
     int force_ksplit;    // autotuner: split-K factor (0 = heuristic)
     int cps;         // split-K: channel chunks per split (set by the launcher)
     float* part;     // split-K partial buffer (set by the launcher) or null
+    int wb_c8p, wb_npad;   // bf16 mode: W points at the packed image [KW][wb_c8p][wb_npad][8] (wun_bf16.hip)
 };
 
 // Weight/bias gradient launch:  P[split][ (k*C + c)*N + n ] and bias row P[split][KW*C*N + n]
@@ -108,6 +109,15 @@ struct HeadArgs {
     float gscale;                                          // 2 / (S*B*Tout*C)
 };
 
+// bf16 mode: one conv's weights, fp32 [KW][C][N] (from the parameter arena or a transposed copy in
+// the workspace) -> packed bf16 image [KW][C8p][Npad][8] in the workspace
+struct PackDesc {
+    long long src_off;   // floats, into params (src_in_ws = 0) or the workspace (1)
+    long long dst_off;   // floats, into the workspace (the image holds KW*C8p*Npad*8 bf16 = half as many floats)
+    int KW, C, N, C8p, Npad;
+    int src_in_ws;
+};
+
 struct WtDesc {      // mode 0: dst[j][n][c] = src[k_last - j*k_step][c][n]
                      // mode 1: dst[j][n][p][c] = src[k_last - 2j + p][c][n] (0 if tap >= k_step (= KW))
     long long src_off;   // into params
@@ -149,5 +159,14 @@ hipError_t launch_fill(float* p, long long n, float val, hipStream_t s);
 hipError_t launch_mfma_probe(const float* a, const float* b, float* d, hipStream_t s);
 void prof_begin();
 std::string prof_end();
+void prof_scope_begin(const char* name, double flops, hipStream_t s, const char* tag);   // HIP-event bracket of the next launch
+void prof_scope_end(hipStream_t s);
+
+// ---- bf16-MFMA speed mode (wun_bf16.hip) ----
+bool conv_bf16_supported(const ConvArgs& a);
+hipError_t launch_conv_bf16(const ConvArgs& a, hipStream_t s);
+hipError_t launch_pack_bf16(const float* params, float* ws, const PackDesc* dev_descs, int ndesc, long long max_items,
+                            hipStream_t s);
+hipError_t launch_mfma_bf16_probe(const float* a, const float* b, float* d, hipStream_t s);
 
 }  // namespace wun

@@ -72,6 +72,25 @@ struct ProfScope {
     }
 };
 
+// explicit begin / end form for launchers in other translation units (one bracket at a time)
+static size_t g_prof_open = (size_t)-1;
+void prof_scope_begin(const char* name, double flops, hipStream_t s, const char* tag) {
+    g_prof_open = (size_t)-1;
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfSlot sl; sl.name = name; sl.tag = tag; sl.flops = flops;
+    if (hipEventCreate(&sl.e0) != hipSuccess || hipEventCreate(&sl.e1) != hipSuccess) return;
+    (void)hipEventRecord(sl.e0, s);
+    g_prof.push_back(sl);
+    g_prof_open = g_prof.size() - 1;
+}
+void prof_scope_end(hipStream_t s) {
+    if (g_prof_open == (size_t)-1) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    (void)hipEventRecord(g_prof[g_prof_open].e1, s);
+    g_prof_open = (size_t)-1;
+}
+
 // JSON: {"kernels": [{"name":..., "launches": n, "ms": total, "flops": total}, ...]}
 std::string prof_end() {
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -631,35 +650,67 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
     }
 }
 
-// sums the split-K partial tiles in a fixed order and applies the conv epilogue
-__global__ void conv_splitk_epilogue_kernel(ConvArgs a, int ksplit) {
+// sums the split-K partial tiles in a fixed order and applies the conv epilogue.  One thread = 4
+// consecutive output positions of one (excerpt, channel) row: the partials are read as 16-byte
+// vectors (rows are padded to 4 floats) and, when the destination allows (F_VEC4), stored as one.
+__global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvArgs a, int ksplit) {
     const int TP = (a.Tout + 3) & ~3;
-    const long long total = (long long)a.B * a.N * a.Tout;
+    const int TP4 = TP >> 2;
+    const long long total = (long long)a.B * a.N * TP4;
     const bool lrelu = (a.flags & F_LRELU) != 0;
     const bool accum = (a.flags & F_ACCUM) != 0;
+    const bool vec = (a.flags & F_VEC4) != 0;
+    const long long sstride = (long long)a.B * a.N * TP;        // floats between consecutive splits
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
-        const int q = (int)(i % a.Tout);
-        const long long bn = i / a.Tout;
+        const int q = (int)(i % TP4) * 4;
+        const long long bn = i / TP4;
         const int ncol = (int)(bn % a.N), b = (int)(bn / a.N);
-        float v = 0.f;
-        for (int ks = 0; ks < ksplit; ++ks)
-            v += a.part[(((long long)ks * a.B + b) * a.N + ncol) * TP + q];
-        if (a.bias != nullptr) v += a.bias[ncol];
-        if (lrelu) v = fmaxf(0.2f * v, v);
-        float* dst; const float* msk; long long idx;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const float* pp = a.part + bn * TP + q;
+        for (int ks = 0; ks < ksplit; ++ks) v += *reinterpret_cast<const f32x4*>(pp + (long long)ks * sstride);
+        const float bvv = (a.bias != nullptr) ? a.bias[ncol] : 0.f;
+        float* dst; const float* msk; long long rowbase;
         if (ncol < a.N0) {
-            idx = (long long)b * a.obs0 + (long long)ncol * a.opitch0 + a.ooff0 + (long long)q * a.ostride;
+            rowbase = (long long)b * a.obs0 + (long long)ncol * a.opitch0 + a.ooff0;
             dst = a.dst0; msk = a.msk0;
         } else {
-            idx = (long long)b * a.obs1 + (long long)(ncol - a.N0) * a.opitch1 + a.ooff1 + (long long)q * a.ostride;
+            rowbase = (long long)b * a.obs1 + (long long)(ncol - a.N0) * a.opitch1 + a.ooff1;
             dst = a.dst1; msk = a.msk1;
         }
-        if (msk != nullptr) v *= (msk[idx] > 0.f) ? 1.f : 0.2f;
-        if (accum) v += dst[idx];
-        dst[idx] = v;
-        if (a.dec != nullptr && ncol < a.N0 && (q & 1) == 0)
-            a.dec[(long long)b * a.decbs + (long long)ncol * a.decpitch + (q >> 1)] = v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[r] += bvv;
+            if (lrelu) v[r] = fmaxf(0.2f * v[r], v[r]);
+        }
+        if (vec && q + 3 < a.Tout) {
+            const long long idx = rowbase + q;
+            if (msk != nullptr) {
+                const f32x4 mk = *reinterpret_cast<const f32x4*>(&msk[idx]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= (mk[r] > 0.f) ? 1.f : 0.2f;
+            }
+            if (accum) v += *reinterpret_cast<const f32x4*>(&dst[idx]);
+            *reinterpret_cast<f32x4*>(&dst[idx]) = v;
+            if (a.dec != nullptr && ncol < a.N0) {
+                float* decrow = a.dec + (long long)b * a.decbs + (long long)ncol * a.decpitch;
+                decrow[q >> 1] = v[0];
+                decrow[(q >> 1) + 1] = v[2];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (q + r < a.Tout) {
+                    const long long idx = rowbase + (long long)(q + r) * a.ostride;
+                    float x = v[r];
+                    if (msk != nullptr) x *= (msk[idx] > 0.f) ? 1.f : 0.2f;
+                    if (accum) x += dst[idx];
+                    dst[idx] = x;
+                    if (a.dec != nullptr && ncol < a.N0 && ((q + r) & 1) == 0)
+                        a.dec[(long long)b * a.decbs + (long long)ncol * a.decpitch + ((q + r) >> 1)] = x;
+                }
+            }
+        }
     }
 }
 
@@ -868,7 +919,7 @@ static hipError_t conv_launch_t(ConvArgs a, int variant, float* part, long long 
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || ksplit == 1) return e;
-    const long long total = (long long)a.B * a.N * a.Tout;
+    const long long total = (long long)a.B * a.N * (((a.Tout + 3) & ~3) >> 2);
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, ksplit);
@@ -930,7 +981,7 @@ hipError_t launch_conv(const ConvArgs& a_in, float* part, long long part_cap, hi
     if (a.KW <= 0) {
         // no taps (odd output phase of a transposed stride-2 conv with filter_size 1): the conv is the
         // epilogue of an empty sum -- bias / activation / mask / accumulate through the split-K epilogue
-        const long long total = (long long)a.B * a.N * a.Tout;
+        const long long total = (long long)a.B * a.N * (((a.Tout + 3) & ~3) >> 2);
         if (total <= 0) return hipSuccess;
         long long blocks = (total + 255) / 256;
         if (blocks > 4096) blocks = 4096;

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -50,6 +51,7 @@ static int check_config(const wun_config* c) {
     if (c->num_channels != 1 && c->num_channels != 2) return fail(WUN_ERR_INVALID, "num_channels must be 1 or 2");
     if (c->num_sources < 1 || c->num_sources > 4) return fail(WUN_ERR_UNSUPPORTED, "num_sources must be 1..4");
     if (c->output_type == 1 && c->num_sources < 2) return fail(WUN_ERR_INVALID, "difference output needs >= 2 sources");
+    if (c->compute_dtype != 0 && c->compute_dtype != 1) return fail(WUN_ERR_UNSUPPORTED, "compute_dtype must be 0 (f32) or 1 (bf16)");
     {
         // the head kernels keep every source's output filter in LDS (default 64 KiB dynamic limit)
         const long long sh = c->output_type == 0 ? c->num_sources : c->num_sources - 1;
@@ -133,6 +135,21 @@ struct wun_plan {
     mutable hipStream_t side = nullptr, side2 = nullptr;
     mutable std::vector<hipEvent_t> events;
     mutable size_t ev_next = 0;
+    // transposed weight copies for the input-gradient convs: produced on the side stream during the
+    // forward pass (training mode) so that the backward pass does not start with a 50 us transpose
+    mutable hipEvent_t wt_ev = nullptr;
+    mutable bool wt_ready = false;
+    // bf16-MFMA speed mode (cfg.compute_dtype == 1): packed bf16 images of the conv weights in the
+    // workspace, keyed by where the fp32 weights of a launch live (params arena / transposed copy in ws)
+    struct BfImg { long long off; int c8p, npad; };
+    bool bf16 = false;
+    std::map<std::pair<int, long long>, BfImg> bf_img;       // (1 = in workspace, float offset) -> image
+    std::vector<PackDesc> pack;                              // forward images first, then the dgrad images
+    int npack_fwd = 0;
+    long long pack_max = 0;
+    PackDesc* dev_pack = nullptr;
+    mutable const float* cur_params = nullptr;
+    mutable const float* cur_ws = nullptr;
 };
 
 static long long bump(long long& cur, long long n) {
@@ -319,6 +336,35 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
     p->bott.wt_full = add_wt(p->bott, Kd, Kd - 1, 1);
     for (int j = 0; j < L; ++j) p->up[j].wt_full = add_wt(p->up[j], Ku, Ku - 1, 1);
 
+    // ---- bf16 mode: packed weight images (every conv with >= 8 input channels; the audio-input conv and the
+    // output head stay exact fp32) ----
+    p->bf16 = cfg->compute_dtype == 1;
+    if (p->bf16) {
+        auto add_img = [&](int in_ws, long long src_off, int K, int Cc, int Nn) {
+            if (Cc < 8 || K < 1) return;
+            PackDesc d;
+            d.src_off = src_off; d.src_in_ws = in_ws; d.KW = K; d.C = Cc; d.N = Nn;
+            d.C8p = (Cc + 31) / 32 * 4; d.Npad = (Nn + 63) / 64 * 64;
+            const long long items = (long long)K * d.C8p * d.Npad;
+            d.dst_off = bump(w, items * 4);                     // 8 bf16 = 4 floats per item
+            p->pack.push_back(d);
+            p->pack_max = std::max(p->pack_max, items);
+            p->bf_img[{in_ws, src_off}] = wun_plan::BfImg{d.dst_off, d.C8p, d.Npad};
+        };
+        for (int i = 0; i < L; ++i) add_img(0, p->down[i].woff, Kd, p->down[i].Cin, p->down[i].Cout);
+        add_img(0, p->bott.woff, Kd, p->bott.Cin, p->bott.Cout);
+        for (int j = 0; j < L; ++j) add_img(0, p->up[j].woff, Ku, p->up[j].Cin, p->up[j].Cout);
+        p->npack_fwd = (int)p->pack.size();
+        // input-gradient convs: "input channels" = the forward conv's Cout, outputs = its Cin
+        for (int i = 1; i < L; ++i) {
+            const ConvLayer& cl = p->down[i];
+            add_img(1, cl.wt_full, cl.KW, cl.Cout, cl.Cin);
+            if (!same) for (int ph = 0; ph < 2; ++ph) add_img(1, cl.wt_ph[ph], cl.Jp[ph], cl.Cout, cl.Cin);
+        }
+        add_img(1, p->bott.wt_full, Kd, p->bott.Cout, p->bott.Cin);
+        for (int j = 0; j < L; ++j) add_img(1, p->up[j].wt_full, Ku, p->up[j].Cout, p->up[j].Cin);
+    }
+
     // ---- wgrad partial buffer: max over layers of (total splits) * (kernel + bias floats) ----
     long long pmax = 0;
     // floats per split in the tile-major partial buffer, worst-case tile padding (384 rows x 80 columns)
@@ -372,6 +418,11 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
             (void)hipGetLastError();
         }
     }
+    if (!p->pack.empty()) {
+        hipError_t e = hipMalloc((void**)&p->dev_pack, p->pack.size() * sizeof(PackDesc));
+        if (e == hipSuccess) e = hipMemcpy(p->dev_pack, p->pack.data(), p->pack.size() * sizeof(PackDesc), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { p->dev_pack = nullptr; (void)hipGetLastError(); }
+    }
     *out = p;
     return WUN_OK;
 }
@@ -379,8 +430,10 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
 extern "C" void wun_plan_destroy(wun_plan* p) {
     if (!p) return;
     if (p->dev_wt) (void)hipFree(p->dev_wt);
+    if (p->dev_pack) (void)hipFree(p->dev_pack);
     for (auto e : p->events) (void)hipEventDestroy(e);
     if (p->tev0) { (void)hipEventDestroy(p->tev0); (void)hipEventDestroy(p->tev1); }
+    if (p->wt_ev) (void)hipEventDestroy(p->wt_ev);
     if (p->side) (void)hipStreamDestroy(p->side);
     if (p->side2) (void)hipStreamDestroy(p->side2);
     delete p;
@@ -510,6 +563,16 @@ static float time_launch(const wun_plan* p, hipStream_t s, const std::function<h
 static hipError_t conv_dispatch(const wun_plan* p, ConvArgs a, float* part, long long cap, hipStream_t s) {
     std::vector<ConvChoice>& vec = p->in_bwd ? p->conv_bwd : p->conv_fwd;
     const size_t idx = p->ci++;
+    if (p->bf16 && conv_bf16_supported(a)) {
+        // bf16-MFMA speed mode: same launch, operands rounded to bf16, weights from the packed image
+        const bool in_ws = a.W >= p->cur_ws && a.W < p->cur_ws + p->ws;
+        auto it = p->bf_img.find({in_ws ? 1 : 0, (long long)(a.W - (in_ws ? p->cur_ws : p->cur_params))});
+        if (it != p->bf_img.end()) {
+            a.W = p->cur_ws + it->second.off;
+            a.wb_c8p = it->second.c8p; a.wb_npad = it->second.npad;
+            return launch_conv_bf16(a, s);
+        }
+    }
     if (p->tune_mode == 1) {
         if (vec.size() <= idx) vec.resize(idx + 1, ConvChoice{-1, 0});
         ConvChoice cands[640];
@@ -554,6 +617,24 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
     hipStream_t s2 = (p->side && !g_profiling && p->tune_mode != 1) ? p->side : s;   // side stream (skip-window convs)
     bool side_used = false;
 
+    p->cur_params = params; p->cur_ws = ws;
+    if (p->bf16) {
+        if (!p->dev_pack) return fail(WUN_ERR_HIP, "plan was created without a usable HIP device");
+        HIP_TRY(launch_pack_bf16(params, ws, p->dev_pack, p->npack_fwd, p->pack_max, s));
+    }
+    p->wt_ready = false;
+    if (training && !p->wt.empty() && p->dev_wt && s2 != s) {
+        // the backward pass will need tap-flipped / transposed copies of every kernel: make them now,
+        // beside the forward convs (they depend on the parameters only)
+        if (!p->wt_ev) HIP_TRY(hipEventCreateWithFlags(&p->wt_ev, hipEventDisableTiming));
+        if ((rc0 = stream_dep(p, s, s2))) return rc0;
+        HIP_TRY(launch_make_wt(params, ws, p->dev_wt, (int)p->wt.size(), p->wt_max, s2));
+        if (p->bf16)
+            HIP_TRY(launch_pack_bf16(params, ws, p->dev_pack + p->npack_fwd, (int)p->pack.size() - p->npack_fwd, p->pack_max, s2));
+        HIP_TRY(hipEventRecord(p->wt_ev, s2));
+        p->wt_ready = true;
+        side_used = true;
+    }
     HIP_TRY(launch_btc_to_ncw(mix_btc, ws + p->mix_ncw.off, p->B, p->Tin, p->C, p->mix_ncw.pitch, s));
 
     const Buf* x = &p->mix_ncw;
@@ -794,7 +875,15 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
         return sig.ready(floor, s2);
     };
 
-    HIP_TRY(launch_make_wt(params, ws, p->dev_wt, (int)p->wt.size(), p->wt_max, s));
+    if (p->wt_ready) {
+        HIP_TRY(hipStreamWaitEvent(s, p->wt_ev, 0));       // made during the forward pass
+        p->wt_ready = false;
+    } else {
+        HIP_TRY(launch_make_wt(params, ws, p->dev_wt, (int)p->wt.size(), p->wt_max, s));
+        if (p->bf16)
+            HIP_TRY(launch_pack_bf16(params, ws, p->dev_pack + p->npack_fwd, (int)p->pack.size() - p->npack_fwd, p->pack_max, s));
+    }
+    p->cur_params = params; p->cur_ws = ws;
 
     // ---- head: loss, d(pre-activation), d(feature map) ----
     HeadArgs h = head_args(p, params, ws, const_cast<float*>(outputs), 1);
@@ -916,7 +1005,7 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
                 f.Tin = d.t_dec; f.KW = cl.J0; f.kw_full = Kd; f.shift = cl.J0 - 1; f.W = ws + cl.wt_ph2;
                 f.N = f.N0 = d.cin; f.Tout = (d.t_in + 1) / 2; f.Tlim = d.t_in; f.flags = F_PHASE2;
                 set_dst0(f, ws, p->dz_dec[i - 1], 0, &p->dec[i - 1]);
-                if ((d.cin & 3) == 0 && f.Tout >= 256 && conv_natural_wgs_phase2(f) >= 256) {
+                if (!p->bf16 && (d.cin & 3) == 0 && f.Tout >= 256 && conv_natural_wgs_phase2(f) >= 256) {
                     HIP_TRY(conv_dispatch(p, f, ws + p->conv_part_off, p->conv_part_floats / 2, s));
                 } else {
                     for (int ph = 0; ph < 2; ++ph) {
@@ -972,10 +1061,10 @@ static std::string tune_header(const wun_plan* p, size_t ncf, size_t ncb, size_t
     const wun_config& c = p->cfg;
     snprintf(line, sizeof(line),
              "wun-tune 2 order=%s variants=%d B=%d Tin=%lld L=%d F=%d K=%d,%d,%d ups=%d out=%d ctx=%d S=%d C=%d act=%d "
-             "arena=%lld cf=%zu cb=%zu wg=%zu",
+             "dt=%d arena=%lld cf=%zu cb=%zu wg=%zu",
              WUN_TUNE_ORDER, conv_num_variants(), p->B, (long long)p->Tin, p->L, c.num_initial_filters, c.filter_size,
              c.merge_filter_size, c.output_filter_size, c.upsampling, c.output_type, c.context, c.num_sources,
-             c.num_channels, c.output_activation, (long long)p->arena, ncf, ncb, nwg);
+             c.num_channels, c.output_activation, c.compute_dtype, (long long)p->arena, ncf, ncb, nwg);
     return line;
 }
 
@@ -1249,6 +1338,50 @@ extern "C" int wun_op_conv1d_ex(const float* x0, int c0, const float* x1, int c1
     return WUN_OK;
 }
 
+// bf16-MFMA conv as a single operator: packs w (fp32 [K][Cin][Cout]) into the bf16 image in `scratch`
+// (>= wun_op_conv1d_bf16_scratch floats), then runs the bf16 kernel.  Same semantics as wun_op_conv1d.
+extern "C" int64_t wun_op_conv1d_bf16_scratch(int cin, int cout, int k) {
+    return (int64_t)k * ((cin + 31) / 32 * 4) * ((cout + 63) / 64 * 64) * 4 + 64;
+}
+
+extern "C" int wun_op_conv1d_bf16(const float* x, const float* w, const float* bias, float* y, float* scratch,
+                                  int batch, int cin, int cout, int k, int t_in, int t_out, int stride, int pad_left,
+                                  int lrelu, void* stream) {
+    if (!x || !w || !y || !scratch) return fail(WUN_ERR_INVALID, "null argument");
+    if (stride != 1 && stride != 2) return fail(WUN_ERR_UNSUPPORTED, "stride must be 1 or 2");
+    hipStream_t s = (hipStream_t)stream;
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = batch; a.ostride = 1;
+    op_src(a, x, cin, t_in);
+    a.loader = stride == 2 ? LOADER_DEINT : LOADER_DIRECT;
+    a.Tin = t_in; a.shift = pad_left; a.bias = bias; a.KW = k; a.N = a.N0 = cout; a.Tout = t_out;
+    a.flags = lrelu ? F_LRELU : 0;
+    a.dst0 = y; a.obs0 = (long long)cout * t_out; a.opitch0 = t_out;
+    if (!conv_bf16_supported(a)) return fail(WUN_ERR_UNSUPPORTED, "shape not served by the bf16 kernel (cin < 8 or k > 15)");
+    float* img = (float*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
+    PackDesc d;
+    d.src_off = 0; d.src_in_ws = 0; d.dst_off = 0; d.KW = k; d.C = cin; d.N = cout;
+    d.C8p = (cin + 31) / 32 * 4; d.Npad = (cout + 63) / 64 * 64;
+    PackDesc* dd = nullptr;
+    HIP_TRY(hipMalloc((void**)&dd, sizeof(PackDesc)));
+    hipError_t e = hipMemcpyAsync(dd, &d, sizeof(d), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = launch_pack_bf16(w, img, dd, 1, (long long)k * d.C8p * d.Npad, s);
+    a.W = img; a.wb_c8p = d.C8p; a.wb_npad = d.Npad;
+    if (e == hipSuccess) e = launch_conv_bf16(a, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(dd);
+    HIP_TRY(e);
+    return WUN_OK;
+}
+
+/* Lane layout probe of v_mfma_f32_16x16x32_bf16: d[16][16] = bf16(a[16][32]) * bf16(b[32][16]). */
+extern "C" int wun_op_mfma_bf16_probe(const float* a, const float* b, float* d, void* stream) {
+    if (!a || !b || !d) return fail(WUN_ERR_INVALID, "null argument");
+    HIP_TRY(launch_mfma_bf16_probe(a, b, d, (hipStream_t)stream));
+    return WUN_OK;
+}
+
 extern "C" int wun_op_mfma_probe(const float* a, const float* b, float* d, void* stream) {
     if (!a || !b || !d) return fail(WUN_ERR_INVALID, "null argument");
     HIP_TRY(launch_mfma_probe(a, b, d, (hipStream_t)stream));
@@ -1266,4 +1399,4 @@ extern "C" int wun_profile_end(char* json_out, int64_t capacity) {
 }
 
 extern "C" const char* wun_last_error(void) { return g_err.c_str(); }
-extern "C" const char* wun_version(void) { return "wun 0.1 (gfx950, fp32 MFMA 16x16x4)"; }
+extern "C" const char* wun_version(void) { return "wun 0.2 (gfx950, fp32 MFMA 16x16x4 + bf16 MFMA 16x16x32 speed mode)"; }

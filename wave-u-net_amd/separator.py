@@ -21,9 +21,12 @@ from .config import finalize
 _UPS = {"linear": 0, "learned": 1}
 _OUT = {"direct": 0, "difference": 1}
 _ACT = {"tanh": 0, "linear": 1}
+_DTYPE = {"f32": 0, "bf16": 1}      # extension key model_config["compute_dtype"] (no reference counterpart)
 
 
 def _wun_config(cfg):
+    if cfg.get("compute_dtype", "f32") not in _DTYPE:
+        raise NotImplementedError("compute_dtype=%r" % (cfg["compute_dtype"],))
     for key, table in (("upsampling", _UPS), ("output_type", _OUT), ("output_activation", _ACT)):
         if cfg[key] not in table:
             raise NotImplementedError("%s=%r" % (key, cfg[key]))   # UnetAudioSeparator.py:136,144
@@ -31,7 +34,7 @@ def _wun_config(cfg):
         cfg["num_layers"], cfg["num_initial_filters"], cfg["filter_size"], cfg["merge_filter_size"],
         cfg["input_filter_size"], cfg["output_filter_size"], _UPS[cfg["upsampling"]],
         _OUT[cfg["output_type"]], 1 if cfg["context"] else 0, len(cfg["source_names"]),
-        1 if cfg["mono_downmix"] else 2, _ACT[cfg["output_activation"]])
+        1 if cfg["mono_downmix"] else 2, _ACT[cfg["output_activation"]], _DTYPE[cfg.get("compute_dtype", "f32")])
 
 
 class _Plan(object):
