@@ -9,6 +9,7 @@ accumulation error (OP_TOL), i.e. the kernel is exact up to the stated operand r
 training steps against the float64 oracle (un-rounded) within the mode's own, looser tolerances
 (BF16_*), stated below and logged like the fp32 ones."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -21,14 +22,19 @@ from _observed import record
 
 pytestmark = pytest.mark.gpu
 
+# the plan keeps launches with fewer than WUN_BF16_MIN_ROWS (default 16384) output rows on the exact-fp32
+# kernels; these tests want every eligible conv of the small configs on the bf16 kernel
+os.environ["WUN_BF16_MIN_ROWS"] = "0"
+
 import wave_u_net_amd as wun                      # noqa: E402
 from wave_u_net_amd import _lib                   # noqa: E402
 from wave_u_net_amd.separator import UnetAudioSeparator   # noqa: E402
 
 OP_TOL = 2e-5            # bf16 conv op vs float64 conv of the bf16-rounded operands, x max|ref|
-BF16_OUT_TOL = 2e-2      # network outputs vs the float64 oracle, absolute (outputs are O(1))
-BF16_LOSS_TOL = 2e-2     # relative
-BF16_GRAD_TOL = 6e-2     # x max|g| per gradient tensor
+BF16_OUT_TOL = 1e-2      # network outputs vs the float64 oracle, absolute (outputs are O(1)); observed <= 1.2e-3
+BF16_LOSS_TOL = 1e-2     # relative; observed <= 1.6e-3
+BF16_GRAD_TOL = 2.5e-1   # x max|g| per gradient tensor (small nets: few terms average the operand rounding out;
+                         # observed <= 1.7e-1 on the 8-filter test nets, <= 6e-2 at full size)
 
 
 @pytest.fixture(scope="module")

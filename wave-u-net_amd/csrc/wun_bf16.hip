@@ -11,15 +11,15 @@
 // B[k = 8*(l>>4) .. +7][j = l&15] and receives D[i = 4*(l>>4)+r][j = l&15].
 //
 // LDS images (per pipeline buffer):
-//   X  [plane][row = time][32 channels] bf16, row pitch 96 B (64 B of data + 32 B pad: conflict-free
-//      for the ds_read_b128 lane groups of gfx950 at every tap offset); the stride-2 loader keeps
+//   X  [plane][row = time][32*NCK channels] bf16, row pitch 64*NCK + 32 B (the 32 B pad makes the
+//      ds_read_b128 lane groups of gfx950 conflict-free at every tap offset); the stride-2 loader keeps
 //      even / odd input samples in two planes so tap k reads plane k&1 at row q + (k>>1)
 //   W  [tap][channel group of 8][cout][8 channels] bf16 -- copied verbatim from the pre-packed
 //      bf16 weight image (pack_bf16_kernel), so a B fragment is one aligned 16-byte read and 16
 //      lanes read 256 contiguous bytes
-// Pipeline: stage = (32-channel chunk, group of TG taps); weights of stage s+1 and the input window
-// of chunk c+1 are fetched into registers while the MFMAs of stage s run and written to the other
-// LDS buffer afterwards; one barrier per stage.
+// Pipeline: stage = (NCK chunks of 32 channels) x all taps; while the MFMAs of stage s run, the weights
+// of stage s+1 stream global -> LDS (global_load_lds) and its input window is fetched into registers,
+// rounded and written to the other LDS buffer afterwards; one barrier per stage.
 #include "wun_internal.h"
 
 #include <cstdio>
@@ -43,29 +43,36 @@ __device__ __forceinline__ int xcd_block(int bid, int grid) {
     return xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
 }
 
-#define WUN_BF_XPB 96          // bytes per X row in LDS
 #define WUN_BF_KMAX 15         // taps
 
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
+
+// X items (16-byte slots = 8 channels of one time step) a thread stages per stage, by tile height
+template <int MT> struct BfXit { static constexpr int v = MT == 4 ? 9 : (MT == 2 ? 7 : 4); };
+
+// Stage = NCK chunks of 32 input channels x ALL taps (so a stage carries enough MFMAs -- ~12 tap-chunks --
+// to cover a global-memory round trip).  Weights of stage s+1 go global -> LDS directly
+// (global_load_lds, 16 bytes per lane: no registers, the image is already in LDS order); the input window
+// of stage s+1 is fetched into registers while stage s computes and written (bf16-rounded) afterwards.
 template <int MT, int NW>
-__global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int nNT, int TG, int ROWS) {
+__global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int nNT, int NCK, int ROWS) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int WT = 4;
     constexpr int TT = WT * MT * 16;
     constexpr int NT = NW * 16;
+    constexpr int XIT = BfXit<MT>::v;
     const bool deint = (a.loader == LOADER_DEINT);
     const int planes = deint ? 2 : 1;
     const int KW = a.KW;
-    const int G = (KW + TG - 1) / TG;                       // tap groups per chunk
-    // compile-time staging trip counts (upper bounds; the live count is checked at run time)
-    constexpr int XIT = (8 * (TT + (WUN_BF_KMAX + 1) / 2) + 255) / 256 > (4 * (TT + WUN_BF_KMAX - 1) + 255) / 256
-                            ? (8 * (TT + (WUN_BF_KMAX + 1) / 2) + 255) / 256
-                            : (4 * (TT + WUN_BF_KMAX - 1) + 255) / 256;
-    constexpr int WITMAX = (5 * 4 * NT + 255) / 256;        // TG <= 5
+    const int XPB = 64 * NCK + 32;                          // bytes per X row: conflict-free for ds_read_b128 at every tap
+    const int C8S = 4 * NCK;                                // 8-channel groups per stage
 
-    const int xbytes = planes * ROWS * WUN_BF_XPB;
-    const int wbytes = TG * 4 * NT * 16;
-    unsigned char* Xs = smem;                               // two X buffers, then two W buffers
-    unsigned char* Ws = smem + 2 * xbytes;
+    const int xbytes = planes * ROWS * XPB;
+    const int wbytes = KW * C8S * NT * 16;
+    const int nbuf = (a.C0 + a.C1 + 32 * NCK - 1) / (32 * NCK) > 1 ? 2 : 1;   // one stage: nothing to double-buffer
+    unsigned char* Xs = smem;                               // nbuf X buffers, then nbuf W buffers
+    unsigned char* Ws = smem + nbuf * xbytes;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -78,8 +85,8 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
     const int q0 = tt * TT, n0 = nt * NT;
     const int wt0 = wave * MT * 16;
     const int Ctot = a.C0 + a.C1;
-    const int nchunks = (Ctot + 31) / 32;
-    const int S = nchunks * G;
+    const int CKW = 32 * NCK;
+    const int S = (Ctot + CKW - 1) / CKW;
 
     const float* src0b = a.src0 + (long long)b * a.bs0 + a.off0;
     const float* src1b = (a.src1 != nullptr) ? a.src1 + (long long)b * a.bs1 + a.off1 : src0b;
@@ -91,12 +98,11 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
         for (int n = 0; n < NW; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     float xreg[XIT][8];
-    u32x4 wreg[WITMAX];
-    const int nxitems = planes * ROWS * 4;                  // (channel group, plane, row) items per chunk
-    const int nwitems = TG * 4 * NT;                        // 16-byte weight items per stage
+    const int nxitems = planes * ROWS * C8S;                // (channel group, plane, row) items per stage (<= XIT*256: launcher)
+    const int nwitems = KW * C8S * NT;                      // 16-byte weight items per stage
 
-    // chunk-invariant state of the X items this thread stages, two registers per item:
-    //   xti[i] = clamped source time | channel group << 26 | time-valid << 28 | item-live << 29
+    // stage-invariant state of the X items this thread stages, two registers per item:
+    //   xti[i] = clamped source time | channel group << 24 | time-valid << 28 | item-live << 29
     //   xlo[i] = byte offset of the item's 16-byte slot in the LDS image
     int xti[XIT], xlo[XIT];
 #pragma unroll
@@ -110,18 +116,18 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
         const int row = pr - pl * ROWS;
         const int t = (deint ? 2 * (q0 + row) + pl : q0 + row) - a.shift;
         const bool tok = t >= 0 && t < a.Tin;
-        const int tc = t < 0 ? 0 : (t > a.Tin - 1 ? a.Tin - 1 : t);          // Tin < 2^26 (checked by the launcher)
-        xti[i] = tc | (c8l << 26) | ((tok ? 1 : 0) << 28) | ((live ? 1 : 0) << 29);
-        xlo[i] = (pl * ROWS + row) * WUN_BF_XPB + c8l * 16;
+        const int tc = t < 0 ? 0 : (t > a.Tin - 1 ? a.Tin - 1 : t);          // Tin < 2^24 (checked by the launcher)
+        xti[i] = tc | (c8l << 24) | ((tok ? 1 : 0) << 28) | ((live ? 1 : 0) << 29);
+        xlo[i] = (pl * ROWS + row) * XPB + c8l * 16;
     }
 
-    // ---- global -> registers ----
-    auto load_x = [&](int chunk) {
+    // ---- X: global -> registers, registers -> LDS (bf16, zero fill) ----
+    auto load_x = [&](int st) {
 #pragma unroll
         for (int i = 0; i < XIT; ++i) {
             if (i * 256 < nxitems) {                         // uniform
-                const int t = xti[i] & 0x3FFFFFF;
-                const int cbase = chunk * 32 + ((xti[i] >> 26) & 3) * 8;
+                const int t = xti[i] & 0xFFFFFF;
+                const int cbase = st * CKW + ((xti[i] >> 24) & 15) * 8;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     int c = cbase + e;
@@ -132,13 +138,13 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
             }
         }
     };
-    auto store_x = [&](int chunk, int buf) {
+    auto store_x = [&](int st, int buf) {
         unsigned char* xb = Xs + buf * xbytes;
 #pragma unroll
         for (int i = 0; i < XIT; ++i) {
             if (i * 256 < nxitems && ((xti[i] >> 29) & 1)) {
                 const bool tok = (xti[i] >> 28) & 1;
-                const int cbase = chunk * 32 + ((xti[i] >> 26) & 3) * 8;
+                const int cbase = st * CKW + ((xti[i] >> 24) & 15) * 8;
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (tok && cbase + e < Ctot) ? xreg[i][e] : 0.f;
@@ -147,75 +153,74 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
             }
         }
     };
-    // weights: a.W points at the packed bf16 image [KW][C8p][Npad][8]; a.wb_c8p / a.wb_npad give its shape
+    // ---- W: packed bf16 image [KW][C8p][Npad][8] -> LDS [tap][channel group][cout][8], 16 bytes per lane ----
     const unsigned short* Wb = reinterpret_cast<const unsigned short*>(a.W);
-    auto load_w = [&](int s) {
-        const int chunk = s / G, g = s - chunk * G;
-        const int j0 = g * TG;
-#pragma unroll
-        for (int i = 0; i < WITMAX; ++i) {
-            const int it = tid + i * 256;
-            if (i * 256 < nwitems) {
-                const int itc = it < nwitems ? it : nwitems - 1;
-                const int jg = itc / (4 * NT);
-                const int r = itc - jg * (4 * NT);
-                const int c8l = r / NT, n = r - c8l * NT;
-                int j = j0 + jg;
-                j = j < KW ? j : KW - 1;                     // taps past the filter are never read by the MFMA loop
-                const long long off = (((long long)j * a.wb_c8p + chunk * 4 + c8l) * a.wb_npad + n0 + n) * 8;
-                wreg[i] = *reinterpret_cast<const u32x4*>(Wb + off);
+    auto dma_w = [&](int st, int buf) {
+        unsigned char* wbuf = Ws + buf * wbytes;
+        const int per_tap = C8S * NT;                           // 16-byte items per tap
+        for (int j = 0; j < KW; ++j) {
+            const unsigned short* wj = Wb + (((long long)j * a.wb_c8p + st * C8S) * a.wb_npad + n0) * 8;
+            for (int i0 = 0; i0 < per_tap; i0 += 256) {
+                const int r = i0 + tid;
+                if (r < per_tap) {
+                    const int c8l = r / NT, n = r - c8l * NT;   // NT is a compile-time constant: no integer division
+                    __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(wj + ((long long)c8l * a.wb_npad + n) * 8),
+                                                     (lds_void_t*)(wbuf + (j * per_tap + i0 + wave * 64) * 16), 16, 0, 0);
+                }
             }
         }
     };
-    auto store_w = [&](int buf) {
-        unsigned char* wbuf = Ws + buf * wbytes;
-#pragma unroll
-        for (int i = 0; i < WITMAX; ++i) {
-            const int it = tid + i * 256;
-            if (i * 256 < nwitems && it < nwitems) *reinterpret_cast<u32x4*>(wbuf + it * 16) = wreg[i];
-        }
-    };
 
-    // ---- MFMA over the taps of one stage ----
-    auto run_stage = [&](int s) {
-        const int chunk = s / G, g = s - chunk * G;
-        const int j0 = g * TG;
-        int j1 = j0 + TG; if (j1 > KW) j1 = KW;
-        const unsigned char* xb = Xs + (chunk & 1) * xbytes;
-        const unsigned char* wbuf = Ws + (s & 1) * wbytes;
-        for (int j = j0; j < j1; ++j) {
+    // ---- MFMA over all (tap, channel sub-chunk) k-steps of one stage; the operands of k-step i+1 are read from
+    // LDS before the MFMAs of k-step i issue (two register sets), so LDS latency hides behind the matrix pipe ----
+    auto run_stage = [&](int st) {
+        const unsigned char* xb = Xs + (st & 1) * xbytes + (wt0 + li) * XPB + lg * 16;
+        const unsigned char* wbuf = Ws + (st & 1) * wbytes + (lg * NT + li) * 16;
+        const int nsteps = KW * NCK;
+        auto ldops = [&](int j, int sc, bf16x8 (&av)[MT], bf16x8 (&bv)[NW]) {
             const int pl = deint ? (j & 1) : 0;
             const int ro = deint ? (j >> 1) : j;
-            const unsigned char* xa = xb + (pl * ROWS + wt0 + li + ro) * WUN_BF_XPB + lg * 16;
-            const unsigned char* wp = wbuf + (((j - j0) * 4 + lg) * NT + li) * 16;
-            bf16x8 av[MT], bv[NW];
+            const unsigned char* xa = xb + (pl * ROWS + ro) * XPB + sc * 64;
+            const unsigned char* wp = wbuf + ((j * C8S + sc * 4) * NT) * 16;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) av[m] = *reinterpret_cast<const bf16x8*>(xa + m * 16 * WUN_BF_XPB);
+            for (int m = 0; m < MT; ++m) av[m] = *reinterpret_cast<const bf16x8*>(xa + m * 16 * XPB);
 #pragma unroll
             for (int n = 0; n < NW; ++n) bv[n] = *reinterpret_cast<const bf16x8*>(wp + n * 16 * 16);
+        };
+        auto mm = [&](const bf16x8 (&av)[MT], const bf16x8 (&bv)[NW]) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < NW; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[m], bv[n], acc[m][n], 0, 0, 0);
+        };
+        bf16x8 a0[MT], b0[NW], a1[MT], b1[NW];
+        int j = 0, sc = 0;
+        auto advance = [&]() { if (++sc == NCK) { sc = 0; ++j; } };
+        ldops(0, 0, a0, b0);
+        for (int i = 0; i < nsteps; i += 2) {
+            advance();
+            if (i + 1 < nsteps) ldops(j, sc, a1, b1);
+            mm(a0, b0);
+            advance();
+            if (i + 2 < nsteps) ldops(j, sc, a0, b0);
+            if (i + 1 < nsteps) mm(a1, b1);
         }
     };
 
-    // ---- pipeline ----
+    // ---- pipeline: one barrier per stage ----
+    dma_w(0, 0);
     load_x(0);
-    load_w(0);
     store_x(0, 0);
-    store_w(0);
     __syncthreads();
-    for (int s = 0; s < S; ++s) {
-        const int chunk = s / G, g = s - chunk * G;
-        const bool has_next = s + 1 < S;
-        const bool next_chunk = chunk + 1 < nchunks;
-        if (has_next) load_w(s + 1);
-        if (g == 0 && next_chunk) load_x(chunk + 1);
-        run_stage(s);
-        if (has_next) store_w((s + 1) & 1);
-        if (g == G - 1 && next_chunk) store_x(chunk + 1, (chunk + 1) & 1);
+    for (int st = 0; st < S; ++st) {
+        const bool has_next = st + 1 < S;
+        if (has_next) {
+            dma_w(st + 1, (st + 1) & 1);
+            load_x(st + 1);
+        }
+        run_stage(st);
+        if (has_next) store_x(st + 1, (st + 1) & 1);
         __syncthreads();
     }
 
@@ -285,20 +290,48 @@ bool conv_bf16_supported(const ConvArgs& a) {
     if (a.flags & F_PHASE2) return false;
     if (a.C0 + a.C1 < 8) return false;                    // the 1-/2-channel audio input stays on the exact-fp32 kernel
     if (a.KW < 1 || a.KW > WUN_BF_KMAX) return false;
-    if (a.Tin >= (1 << 26)) return false;
+    if (a.Tin >= (1 << 24)) return false;
     return true;
+}
+
+// Few output positions: the launch is latency-bound, not matrix-pipe-bound, and the exact-fp32 kernels
+// (batch-folded tiles, split-K) serve it at least as fast -- those levels keep exact arithmetic in the
+// speed mode.  min_rows: the plan's threshold on B * Tout (WUN_BF16_MIN_ROWS, default 16384).
+bool conv_bf16_preferred(const ConvArgs& a, long long min_rows) {
+    return conv_bf16_supported(a) && (long long)a.B * a.Tout >= min_rows;
 }
 
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+static inline int bf16_rows(const ConvArgs& a, int TT) {
+    return a.loader == LOADER_DEINT ? TT + (a.KW + 1) / 2 : TT + a.KW - 1;
+}
+static inline size_t bf16_lds(const ConvArgs& a, int TT, int NT, int nck) {
+    const int planes = a.loader == LOADER_DEINT ? 2 : 1;
+    const int nbuf = (a.C0 + a.C1 + 32 * nck - 1) / (32 * nck) > 1 ? 2 : 1;
+    return nbuf * ((size_t)planes * bf16_rows(a, TT) * (64 * nck + 32) + (size_t)a.KW * 4 * nck * NT * 16);
+}
+// channel chunks per stage: enough tap-chunks (~12) per stage to cover a memory round trip, within the
+// X-staging register budget and 160 KiB of LDS
+static int bf16_pick_nck(const ConvArgs& a, int TT, int NT, int xit) {
+    const int planes = a.loader == LOADER_DEINT ? 2 : 1;
+    int nck = (12 + a.KW - 1) / a.KW;
+    if (nck > 3) nck = 3;
+    const int maxck = (a.C0 + a.C1 + 31) / 32;
+    if (nck > maxck) nck = maxck;
+    while (nck > 1 && (planes * bf16_rows(a, TT) * 4 * nck > xit * 256 || bf16_lds(a, TT, NT, nck) > 160 * 1024)) --nck;
+    return nck;
+}
+
 template <int MT, int NW>
 static hipError_t conv_bf16_launch_t(ConvArgs a, hipStream_t s) {
     constexpr int TT = 4 * MT * 16, NT = NW * 16;
-    const bool deint = a.loader == LOADER_DEINT;
-    const int ROWS = deint ? TT + (a.KW + 1) / 2 : TT + a.KW - 1;
-    const int TG = a.KW <= 5 ? a.KW : (a.KW <= 10 ? (a.KW + 1) / 2 : (a.KW + 2) / 3);
+    const int NCK = bf16_pick_nck(a, TT, NT, BfXit<MT>::v);
+    const int ROWS = bf16_rows(a, TT);
+    const int planes = a.loader == LOADER_DEINT ? 2 : 1;
+    const size_t lds = bf16_lds(a, TT, NT, NCK);
+    if (lds > 160 * 1024 || planes * ROWS * 4 * NCK > BfXit<MT>::v * 256) return hipErrorInvalidValue;
     const int nTT = (a.Tout + TT - 1) / TT, nNT = (a.N + NT - 1) / NT;
-    const size_t lds = 2 * ((size_t)(deint ? 2 : 1) * ROWS * WUN_BF_XPB + (size_t)TG * 4 * NT * 16);
     auto kern = conv_bf16_kernel<MT, NW>;
     static size_t lds_allowed = 64 * 1024;
     if (lds > lds_allowed) {
@@ -310,9 +343,10 @@ static hipError_t conv_bf16_launch_t(ConvArgs a, hipStream_t s) {
     if (grid <= 0) return hipSuccess;
     char nm[64], tag[160];
     snprintf(nm, sizeof(nm), "conv_bf16_kernel<%d, %d>", MT, NW);
-    snprintf(tag, sizeof(tag), "C=%d N=%d T=%d K=%d ld=%d B=%d grid=%lld", a.C0 + a.C1, a.N, a.Tout, a.KW, a.loader, a.B, grid);
+    snprintf(tag, sizeof(tag), "C=%d N=%d T=%d K=%d ld=%d B=%d nck=%d grid=%lld", a.C0 + a.C1, a.N, a.Tout, a.KW, a.loader, a.B,
+             NCK, grid);
     prof_scope_begin(nm, conv_flops(a), s, tag);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a, nTT, nNT, TG, ROWS);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a, nTT, nNT, NCK, ROWS);
     prof_scope_end(s);
     return hipGetLastError();
 }
@@ -337,7 +371,8 @@ hipError_t launch_conv_bf16(const ConvArgs& a_in, hipStream_t s) {
     }
     const long long cols = (a.N + bestnw * 16 - 1) / (bestnw * 16);
     int mt = 4;
-    while (mt > 1 && ((long long)((a.Tout + 64 * mt - 1) / (64 * mt)) * cols * a.B < 512 || a.Tout <= 32 * mt)) mt >>= 1;
+    while (mt > 1 && ((long long)((a.Tout + 64 * mt - 1) / (64 * mt)) * cols * a.B < 512 || a.Tout <= 32 * mt ||
+                      bf16_lds(a, 64 * mt, bestnw * 16, 1) > 160 * 1024)) mt >>= 1;
 #define WUN_BF(M, N) if (mt == M && bestnw == N) return conv_bf16_launch_t<M, N>(a, s);
     WUN_BF(4, 4) WUN_BF(4, 3) WUN_BF(4, 2)
     WUN_BF(2, 4) WUN_BF(2, 3) WUN_BF(2, 2)

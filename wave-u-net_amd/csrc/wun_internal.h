@@ -164,6 +164,7 @@ void prof_scope_end(hipStream_t s);
 
 // ---- bf16-MFMA speed mode (wun_bf16.hip) ----
 bool conv_bf16_supported(const ConvArgs& a);
+bool conv_bf16_preferred(const ConvArgs& a, long long min_rows);
 hipError_t launch_conv_bf16(const ConvArgs& a, hipStream_t s);
 hipError_t launch_pack_bf16(const float* params, float* ws, const PackDesc* dev_descs, int ndesc, long long max_items,
                             hipStream_t s);

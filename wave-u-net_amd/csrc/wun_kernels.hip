@@ -1162,7 +1162,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a, int nMG
         for (int i = 0; i < WUN_WG_XIT; ++i) {
             int pk = xpk[i];
             asm volatile("" : "+v"(pk));          // keep the unpacking inside the unit loop (no hoisted copies)
-            const int c = cLo + ((pk >> 23) & 255);                   // rows past nCh carry row 0
+            int c = cLo + ((pk >> 23) & 255);                         // rows past nCh carry row 0
+            c = c < Ctot ? c : Ctot - 1;                              // bias-only row group: cLo == Ctot (nothing staged)
             const bool s1 = c >= a.C0;
             const int xro = s1 ? (c - a.C0) * a.pitch1 : c * a.pitch0; // element offset of the source row
             int e = (s1 ? e01 : e00) + (((pk >> 16) & 127) << 2);      // element index inside the row

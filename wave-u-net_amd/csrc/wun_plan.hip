@@ -143,6 +143,7 @@ struct wun_plan {
     // workspace, keyed by where the fp32 weights of a launch live (params arena / transposed copy in ws)
     struct BfImg { long long off; int c8p, npad; };
     bool bf16 = false;
+    long long bf16_min_rows = 16384;                         // smaller launches stay on the exact-fp32 kernels
     std::map<std::pair<int, long long>, BfImg> bf_img;       // (1 = in workspace, float offset) -> image
     std::vector<PackDesc> pack;                              // forward images first, then the dgrad images
     int npack_fwd = 0;
@@ -339,6 +340,7 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
     // ---- bf16 mode: packed weight images (every conv with >= 8 input channels; the audio-input conv and the
     // output head stay exact fp32) ----
     p->bf16 = cfg->compute_dtype == 1;
+    if (const char* e = getenv("WUN_BF16_MIN_ROWS")) p->bf16_min_rows = atoll(e);
     if (p->bf16) {
         auto add_img = [&](int in_ws, long long src_off, int K, int Cc, int Nn) {
             if (Cc < 8 || K < 1) return;
@@ -563,7 +565,7 @@ static float time_launch(const wun_plan* p, hipStream_t s, const std::function<h
 static hipError_t conv_dispatch(const wun_plan* p, ConvArgs a, float* part, long long cap, hipStream_t s) {
     std::vector<ConvChoice>& vec = p->in_bwd ? p->conv_bwd : p->conv_fwd;
     const size_t idx = p->ci++;
-    if (p->bf16 && conv_bf16_supported(a)) {
+    if (p->bf16 && conv_bf16_preferred(a, p->bf16_min_rows)) {
         // bf16-MFMA speed mode: same launch, operands rounded to bf16, weights from the packed image
         const bool in_ws = a.W >= p->cur_ws && a.W < p->cur_ws + p->ws;
         auto it = p->bf_img.find({in_ws ? 1 : 0, (long long)(a.W - (in_ws ? p->cur_ws : p->cur_params))});
