@@ -99,7 +99,6 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
 
     float xreg[XIT][8];
     const int nxitems = planes * ROWS * C8S;                // (channel group, plane, row) items per stage (<= XIT*256: launcher)
-    const int nwitems = KW * C8S * NT;                      // 16-byte weight items per stage
 
     // stage-invariant state of the X items this thread stages, two registers per item:
     //   xti[i] = clamped source time | channel group << 24 | time-valid << 28 | item-live << 29

@@ -75,6 +75,19 @@ struct WgradArgs {
     int force_mtw, force_nw;   // autotuner: geometry overrides (0 = heuristic)
 };
 
+// Narrow weight gradient (wun_narrow.hip): audio-input conv / output head.  Input = virtual concat of two
+// NCW sources as in WgradArgs; dz row n = (s, c), s = n / Nper, at dz + s*zss + b*dzbs + c*dzpitch.
+struct NarrowWgradArgs {
+    const float* src0; const float* src1;
+    long long bs0, bs1;
+    int pitch0, pitch1, off0, off1, C0, C1;
+    int Tin, shift, KW, stride;
+    const float* dz; long long zss, dzbs; int dzpitch;
+    int N, Nper, Tq, B;
+    float* partial;      // [splits][(KW*Ctot + 1) * N]
+    int split_base, nsplit, units_per_split, nQT;
+};
+
 struct ConvChoice { int variant; int ksplit; };
 struct WgradChoice { int mtw, nw, nsplit[2]; };   // per layer: shared tile geometry, split count per part
 
@@ -161,6 +174,15 @@ void prof_begin();
 std::string prof_end();
 void prof_scope_begin(const char* name, double flops, hipStream_t s, const char* tag);   // HIP-event bracket of the next launch
 void prof_scope_end(hipStream_t s);
+
+// ---- narrow weight gradients (wun_narrow.hip) ----
+bool narrow_wgrad_supported(const NarrowWgradArgs& a);
+int narrow_wgrad_units(const NarrowWgradArgs& a);
+int narrow_wgrad_pick_nsplit(const NarrowWgradArgs& a);
+long long narrow_wgrad_partial_floats(const NarrowWgradArgs& a);
+hipError_t launch_narrow_wgrad(NarrowWgradArgs a, hipStream_t s);
+hipError_t launch_narrow_wgrad_reduce(const NarrowWgradArgs& a, const float* partial, int nsplit, float* grads,
+                                      const long long* woff, const long long* boff, hipStream_t s);
 
 // ---- bf16-MFMA speed mode (wun_bf16.hip) ----
 bool conv_bf16_supported(const ConvArgs& a);

@@ -1,0 +1,200 @@
+// Weight gradients of the two "narrow" convolutions of the Wave-U-Net -- the audio-input conv (1 or 2
+// input channels, /root/reference/Models/UnetAudioSeparator.py:98 at i = 0) and the output head (1 or 2
+// output channels per source, /root/reference/Models/OutputLayer.py:8,15) -- as direct reductions on the
+// vector pipe.  Their contraction has no dense channel x channel face (Cin*Cout <= a few dozen), so an MFMA
+// tile is > 90 % padding there (the MFMA weight-gradient kernel ran them at 0.6 and 10 TFLOP/s); they are
+// bound by streaming dz once from HBM.
+//
+//   dW[k][ci][n] = sum_{b,q} x[b][ci][q*SI + k - shift] * dz[b][n][q],   db[n] = sum_{b,q} dz[b][n][q]
+//
+// One workgroup owns a contiguous range of (excerpt, 256-position tile) units.  Per unit the dz rows and
+// the input rows (+ halo) are staged in LDS with coalesced loads; thread (pair p = (ci, n), lane group g)
+// keeps the KT tap accumulators of its pair in registers and walks the tile 4 positions at a time with
+// 16-byte LDS reads (one dz vector, a contiguous x window), i.e. 4*K FMAs per ~6 LDS reads.  At the end the
+// lane groups of a pair are summed through LDS in a fixed order and the workgroup writes one partial
+// vector; narrow_wgrad_reduce_kernel sums the partials in split order (deterministic, no atomics) and
+// scatters to the TF layout [K][Cin][Cout] + bias of each source.
+#include "wun_internal.h"
+
+#include <cstdio>
+
+namespace wun {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define WUN_NW_TQ 256            // output positions per unit
+
+template <int KT, int SI>
+__global__ __launch_bounds__(256) void narrow_wgrad_kernel(NarrowWgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float nlds[];
+    constexpr int TQ = WUN_NW_TQ;
+    constexpr int XWIN = 3 * SI + KT;                       // x values one thread needs for 4 positions
+    constexpr int XV = (XWIN + 3) / 4;                      // as 16-byte vectors
+    constexpr int XW = (TQ * SI + KT - 1 + 4 * XV + 3) / 4 * 4;   // floats per staged input row (window + read slack)
+    const int Ctot = a.C0 + a.C1;
+    const int NP = Ctot * a.N;                              // (ci, n) pairs, <= 256
+    float* Xs = nlds;                                       // [Ctot][XW]
+    float* Zs = Xs + Ctot * XW;                             // [N][TQ]
+    float* red = Zs + a.N * TQ;                             // [G][NP][KT + 1]
+    const int tid = threadIdx.x;
+    const int G = 256 / NP;                                 // lane groups per pair
+    const bool live = tid < G * NP;
+    const int p = live ? tid % NP : 0, g = live ? tid / NP : 0;
+    const int ci = p / a.N, n = p - ci * a.N;
+
+    float acc[KT];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) acc[k] = 0.f;
+    float accb = 0.f;
+
+    const int nunits = a.B * a.nQT;
+    const int u0 = blockIdx.x * a.units_per_split;
+    int u1 = u0 + a.units_per_split;
+    if (u1 > nunits) u1 = nunits;
+    for (int u = u0; u < u1; ++u) {
+        const int b = u / a.nQT, qt = u - b * a.nQT;
+        const int q0 = qt * TQ;
+        const int t0 = q0 * SI - a.shift;
+        __syncthreads();
+        // ---- stage: input rows (zero outside [0, Tin)), dz rows (zero beyond Tq) ----
+        for (int i = tid; i < Ctot * XW; i += 256) {
+            const int c = i / XW, x = i - c * XW;
+            const int t = t0 + x;
+            float v = 0.f;
+            if (t >= 0 && t < a.Tin)
+                v = c < a.C0 ? a.src0[(long long)b * a.bs0 + (long long)c * a.pitch0 + a.off0 + t]
+                             : a.src1[(long long)b * a.bs1 + (long long)(c - a.C0) * a.pitch1 + a.off1 + t];
+            Xs[i] = v;
+        }
+        for (int i = tid; i < a.N * TQ; i += 256) {
+            const int r = i / TQ, q = i - r * TQ;
+            const int s = r / a.Nper, c = r - s * a.Nper;
+            Zs[i] = (q0 + q < a.Tq) ? a.dz[(long long)s * a.zss + (long long)b * a.dzbs + (long long)c * a.dzpitch + q0 + q] : 0.f;
+        }
+        __syncthreads();
+        if (live) {
+            const float* xr = Xs + ci * XW;
+            const float* zr = Zs + n * TQ;
+            for (int q4 = g; q4 < TQ / 4; q4 += G) {
+                const f32x4 z = *reinterpret_cast<const f32x4*>(zr + 4 * q4);
+                float xv[4 * XV];
+#pragma unroll
+                for (int v = 0; v < XV; ++v) {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(xr + 4 * q4 * SI + 4 * v);
+                    xv[4 * v] = t4[0]; xv[4 * v + 1] = t4[1]; xv[4 * v + 2] = t4[2]; xv[4 * v + 3] = t4[3];
+                }
+#pragma unroll
+                for (int k = 0; k < KT; ++k)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[k] = fmaf(xv[r * SI + k], z[r], acc[k]);
+                accb += (z[0] + z[1]) + (z[2] + z[3]);
+            }
+        }
+    }
+    // ---- sum the lane groups of each pair (fixed order), one partial vector per workgroup ----
+    __syncthreads();
+    if (live) {
+        float* r = red + (g * NP + p) * (KT + 1);
+#pragma unroll
+        for (int k = 0; k < KT; ++k) r[k] = acc[k];
+        r[KT] = accb;
+    }
+    __syncthreads();
+    const int P = (a.KW * Ctot + 1) * a.N;
+    float* out = a.partial + (long long)(a.split_base + blockIdx.x) * P;
+    for (int i = tid; i < NP * (a.KW + 1); i += 256) {
+        const int pp = i / (a.KW + 1), k = i - pp * (a.KW + 1);
+        const int cc = pp / a.N, nn = pp - cc * a.N;
+        if (k == a.KW && cc != 0) continue;                 // the bias sum is kept by the ci == 0 pairs
+        float s = 0.f;
+        for (int gg = 0; gg < G; ++gg) s += red[(gg * NP + pp) * (KT + 1) + (k == a.KW ? KT : k)];
+        if (k < a.KW) out[(k * Ctot + cc) * a.N + nn] = s;
+        else out[a.KW * Ctot * a.N + nn] = s;
+    }
+}
+
+// out element (k, ci, n = s*Nper + c) -> source s: weights [K][Ctot][Nper] at woff[s], bias at boff[s]
+__global__ __launch_bounds__(256) void narrow_wgrad_reduce_kernel(const float* partial, int nsplit, int KW, int Ctot, int N,
+                                                                  int Nper, float* grads, long long w0, long long w1,
+                                                                  long long w2, long long w3, long long b0, long long b1,
+                                                                  long long b2, long long b3) {
+    const long long woff[4] = {w0, w1, w2, w3}, boff[4] = {b0, b1, b2, b3};
+    const int P = (KW * Ctot + 1) * N;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += partial[(long long)k * P + i];
+    const int n = i % N, r = i / N;
+    const int src = n / Nper, c = n - src * Nper;
+    if (r < KW * Ctot) grads[woff[src] + (long long)r * Nper + c] = s;
+    else grads[boff[src] + c] = s;
+}
+
+bool narrow_wgrad_supported(const NarrowWgradArgs& a) {
+    const int Ctot = a.C0 + a.C1;
+    if (Ctot * a.N > 256 || Ctot * a.N < 1) return false;
+    if (a.KW < 1 || a.KW > 15) return false;
+    if (a.stride != 1 && a.stride != 2) return false;
+    if (a.stride == 2 && a.KW > 15) return false;
+    if (a.N / a.Nper > 4 || a.N % a.Nper != 0) return false;
+    return true;
+}
+
+static inline int narrow_kt(int KW) { return KW <= 3 ? 3 : 15; }
+
+size_t narrow_wgrad_lds(const NarrowWgradArgs& a) {
+    const int KT = narrow_kt(a.KW), SI = a.stride;
+    const int XV = (3 * SI + KT + 3) / 4;
+    const int XW = (WUN_NW_TQ * SI + KT - 1 + 4 * XV + 3) / 4 * 4;
+    const int Ctot = a.C0 + a.C1, NP = Ctot * a.N, G = 256 / NP;
+    return sizeof(float) * ((size_t)Ctot * XW + (size_t)a.N * WUN_NW_TQ + (size_t)G * NP * (KT + 1));
+}
+
+int narrow_wgrad_units(const NarrowWgradArgs& a) { return a.B * ((a.Tq + WUN_NW_TQ - 1) / WUN_NW_TQ); }
+
+long long narrow_wgrad_partial_floats(const NarrowWgradArgs& a) { return (long long)(a.KW * (a.C0 + a.C1) + 1) * a.N; }
+
+int narrow_wgrad_pick_nsplit(const NarrowWgradArgs& a) {
+    const int units = narrow_wgrad_units(a);
+    int ns = units < 1024 ? units : 1024;                   // ~4 workgroups per CU, each streaming >= 1 unit
+    return ns < 1 ? 1 : ns;
+}
+
+// a.nsplit / a.split_base / a.partial set by the caller
+hipError_t launch_narrow_wgrad(NarrowWgradArgs a, hipStream_t s) {
+    if (!narrow_wgrad_supported(a)) return hipErrorInvalidValue;
+    a.nQT = (a.Tq + WUN_NW_TQ - 1) / WUN_NW_TQ;
+    const int units = a.B * a.nQT;
+    a.units_per_split = (units + a.nsplit - 1) / a.nsplit;
+    const size_t lds = narrow_wgrad_lds(a);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const int KT = narrow_kt(a.KW);
+    char tag[160];
+    snprintf(tag, sizeof(tag), "C=%d N=%d T=%d K=%d stride=%d B=%d nsplit=%d", a.C0 + a.C1, a.N, a.Tq, a.KW, a.stride, a.B, a.nsplit);
+    prof_scope_begin("narrow_wgrad_kernel", 2.0 * a.KW * (double)(a.C0 + a.C1) * a.N * (double)a.Tq * a.B, s, tag);
+#define WUN_NWL(K, S) \
+    if (KT == K && a.stride == S) { \
+        auto kern = narrow_wgrad_kernel<K, S>; \
+        static size_t allowed = 64 * 1024; \
+        if (lds > allowed) { \
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e; \
+            allowed = lds; \
+        } \
+        hipLaunchKernelGGL(kern, dim3((unsigned)a.nsplit), dim3(256), lds, s, a); \
+    }
+    WUN_NWL(3, 1) WUN_NWL(3, 2) WUN_NWL(15, 1) WUN_NWL(15, 2)
+#undef WUN_NWL
+    prof_scope_end(s);
+    return hipGetLastError();
+}
+
+hipError_t launch_narrow_wgrad_reduce(const NarrowWgradArgs& a, const float* partial, int nsplit, float* grads,
+                                      const long long* woff, const long long* boff, hipStream_t s) {
+    const int P = (int)narrow_wgrad_partial_floats(a);
+    hipLaunchKernelGGL(narrow_wgrad_reduce_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, partial, nsplit, a.KW,
+                       a.C0 + a.C1, a.N, a.Nper, grads, woff[0], woff[1], woff[2], woff[3], boff[0], boff[1], boff[2], boff[3]);
+    return hipGetLastError();
+}
+
+}  // namespace wun

@@ -824,6 +824,31 @@ static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const Conv
     return WUN_OK;
 }
 
+// Narrow layers (audio-input conv, output head): direct reduction kernel instead of MFMA tiles.  All parts
+// (a down level's decimated + window positions) write consecutive splits of one partial list; one reduction.
+static int run_narrow_wgrad(const wun_plan* p, NarrowWgradArgs* parts, int nparts, const long long* woff,
+                            const long long* boff, float* ws, float* grads, hipStream_t main, hipStream_t s) {
+    int rcd = stream_dep(p, main, s);
+    if (rcd) return rcd;
+    const long long pcap = p->partial_floats / 2;
+    float* partial = ws + p->partial_off + ((p->side2 && s == p->side2) ? pcap : 0);
+    int total = 0;
+    for (int i = 0; i < nparts; ++i) { parts[i].nsplit = narrow_wgrad_pick_nsplit(parts[i]); total += parts[i].nsplit; }
+    const long long P = narrow_wgrad_partial_floats(parts[0]);
+    while (total * P > pcap && total > nparts) {               // (never in practice: P is a few hundred floats)
+        total = 0;
+        for (int i = 0; i < nparts; ++i) { parts[i].nsplit = (parts[i].nsplit + 1) / 2; total += parts[i].nsplit; }
+    }
+    int done = 0;
+    for (int i = 0; i < nparts; ++i) {
+        parts[i].partial = partial; parts[i].split_base = done;
+        HIP_TRY(launch_narrow_wgrad(parts[i], s));
+        done += parts[i].nsplit;
+    }
+    HIP_TRY(launch_narrow_wgrad_reduce(parts[0], partial, total, grads, woff, boff, s));
+    return WUN_OK;
+}
+
 struct BucketSignal {
     const int64_t* starts; void* const* events; int n; int next;   // buckets in descending start order
     // every gradient at arena offset >= floor is final with respect to stream `st`
@@ -895,7 +920,24 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
     HIP_TRY(launch_head_bwd_off(h, hoff, s));
     HIP_TRY(launch_loss_finish(h.loss_partial, head_bwd_blocks(h),
                                1.0f / ((float)p->S * (float)p->B * (float)p->Tout * (float)p->C), loss, s));
-    for (int sh = 0; sh < p->Sh; ++sh) {
+    bool head_done = false;
+    if (p->Sh > 0) {
+        // every source's output conv in ONE direct-reduction launch (OutputLayer.py:8,15): dz rows = (source, channel)
+        NarrowWgradArgs nw;
+        memset(&nw, 0, sizeof(nw));
+        nw.src0 = ws + p->mix_ncw.off; nw.bs0 = p->mix_ncw.bs; nw.pitch0 = p->mix_ncw.pitch; nw.off0 = p->in_crop_start; nw.C0 = C;
+        nw.src1 = ws + p->upo[L - 1].off; nw.bs1 = p->upo[L - 1].bs; nw.pitch1 = p->upo[L - 1].pitch; nw.off1 = 0; nw.C1 = F;
+        nw.Tin = p->t_feat; nw.shift = h.padl; nw.KW = Ko; nw.stride = 1;
+        nw.dz = h.dpre; nw.zss = h.dps; nw.dzbs = h.dpbs; nw.dzpitch = h.dppitch;
+        nw.N = p->Sh * C; nw.Nper = C; nw.Tq = p->Tout; nw.B = p->B;
+        if (narrow_wgrad_supported(nw)) {
+            long long woff[4] = {0, 0, 0, 0}, boff[4] = {0, 0, 0, 0};
+            for (int sh = 0; sh < p->Sh; ++sh) { woff[sh] = p->head[sh].woff; boff[sh] = p->head[sh].boff; }
+            if ((rc = run_narrow_wgrad(p, &nw, 1, woff, boff, ws, grads, s, wstream()))) return rc;
+            head_done = true;
+        }
+    }
+    for (int sh = 0; sh < p->Sh && !head_done; ++sh) {
         WgradArgs w = wgrad_base(p);
         wset_src0(w, ws, p->mix_ncw, p->in_crop_start, C);
         wset_src1(w, ws, p->upo[L - 1], 0, F);
@@ -970,7 +1012,31 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
         const DownShape& d = p->dsh[i];
         const ConvLayer& cl = p->down[i];
         const Buf& x = (i == 0) ? p->mix_ncw : p->dec[i - 1];
-        if (same) {
+        // the audio-input conv (1 or 2 input channels): direct reduction instead of MFMA tiles
+        NarrowWgradArgs nw[2];
+        bool narrow = false;
+        if (i == 0) {
+            memset(nw, 0, sizeof(nw));
+            for (int k = 0; k < 2; ++k) {
+                nw[k].src0 = ws + x.off; nw[k].bs0 = x.bs; nw[k].pitch0 = x.pitch; nw[k].C0 = d.cin;
+                nw[k].KW = Kd; nw[k].N = nw[k].Nper = d.cout; nw[k].B = p->B;
+            }
+            if (same) {
+                nw[0].Tin = d.t_in; nw[0].shift = padD; nw[0].stride = 1; nw[0].off0 = 0;
+                nw[0].dz = ws + p->dz_skip[0].off; nw[0].dzbs = p->dz_skip[0].bs; nw[0].dzpitch = p->dz_skip[0].pitch; nw[0].Tq = d.t_conv;
+            } else {
+                nw[0].Tin = d.t_in; nw[0].shift = 0; nw[0].stride = 2; nw[0].off0 = 0;
+                nw[0].dz = ws + p->dz_dec[0].off; nw[0].dzbs = p->dz_dec[0].bs; nw[0].dzpitch = p->dz_dec[0].pitch; nw[0].Tq = d.t_dec;
+                nw[1].Tin = d.tc + Kd - 1; nw[1].shift = 0; nw[1].stride = 1; nw[1].off0 = d.cs;
+                nw[1].dz = ws + p->dz_skip[0].off; nw[1].dzbs = p->dz_skip[0].bs; nw[1].dzpitch = p->dz_skip[0].pitch; nw[1].Tq = d.tc;
+            }
+            narrow = narrow_wgrad_supported(nw[0]) && (same || narrow_wgrad_supported(nw[1]));
+        }
+        if (narrow) {
+            const long long woff[4] = {cl.woff, 0, 0, 0}, boff[4] = {cl.boff, 0, 0, 0};
+            if ((rc = run_narrow_wgrad(p, nw, same ? 1 : 2, woff, boff, ws, grads, s, wstream()))) return rc;
+            if ((rc = ready2(cl.woff))) return rc;
+        } else if (same) {
             WgradArgs w = wgrad_base(p);
             wset_src0(w, ws, x, 0, d.cin);
             w.Tin = d.t_in; w.shift = padD; w.KW = Kd;
@@ -1057,7 +1123,7 @@ extern "C" int wun_plan_tune(const wun_plan* p, const float* params, const float
 // Tuning-table header: identifies the plan (every config key that changes a launch), the launch
 // order of this library build and the number of entries per section, so a table written for
 // another plan, another library build or truncated on disk is rejected at import.
-#define WUN_TUNE_ORDER "r2a"      /* bump whenever the order / number of conv or wgrad launches changes */
+#define WUN_TUNE_ORDER "r2b"      /* bump whenever the order / number of conv or wgrad launches changes */
 static std::string tune_header(const wun_plan* p, size_t ncf, size_t ncb, size_t nwg) {
     char line[320];
     const wun_config& c = p->cfg;
