@@ -61,7 +61,8 @@ typedef struct wun_config {
     int32_t compute_dtype;      /* 0 = exact fp32 (v_mfma_f32_16x16x4_f32; the reference's arithmetic), */
                                 /* 1 = bf16 speed mode: conv / input-gradient operands rounded to bf16  */
                                 /*     on v_mfma_f32_16x16x32_bf16, fp32 accumulate; weights, Adam state,*/
-                                /*     activations in HBM, weight gradients and the head stay fp32        */
+                                /*     activations in HBM, the audio-input conv and the head stay fp32; weight    */
+                                /*     gradients use bf16 operands too (launches with few positions stay fp32)   */
 } wun_config;
 
 typedef struct wun_plan wun_plan;
@@ -202,6 +203,10 @@ int wun_op_num_conv_variants(void);
  * (0 = automatic).  Call wun_op_conv1d_wgrad_scratch AFTER forcing: the scratch size depends on it.
  * A geometry the kernel's staging cannot hold for the shape fails with WUN_ERR_UNSUPPORTED. */
 int wun_op_force_wgrad_variant(int mtw, int nw, int nsplit);
+
+/* Test hook: run the following wun_op_conv1d_wgrad calls on the bf16 speed-mode kernel (operands rounded
+ * to bf16, v_mfma_f32_16x16x32_bf16, fp32 accumulate; same tiles / splits / reduction). */
+int wun_op_set_wgrad_bf16(int on);
 
 /* The bf16 speed mode's conv as a single operator (wun_op_conv1d semantics, Cin >= 8, K <= 15): operands
  * are rounded to bf16 (nearest-even), products accumulate in fp32.  scratch: device floats, at least

@@ -111,6 +111,64 @@ def test_op_conv1d_bf16_is_exact_up_to_operand_rounding(lib, case):
     assert err <= OP_TOL
 
 
+BF16_WGRAD_CASES = [
+    # (B, Cin, Cout, K, T, stride, pad_left, same)
+    (2, 24, 48, 15, 700, 1, 0, False),
+    (2, 24, 80, 15, 701, 2, 0, False),
+    (2, 40, 24, 5, 300, 1, 2, True),
+    (16, 48, 56, 15, 95, 2, 0, False),
+    (3, 64, 72, 15, 23, 1, 0, False),
+    (4, 120, 144, 15, 1100, 2, 0, False),
+    (4, 168, 72, 5, 2053, 1, 0, False),
+]
+WGRAD_GEOMS = [(0, 0)] + [(m, n) for m in (1, 2, 4) for n in (1, 2, 3, 4, 5)] + [(6, 1), (6, 2), (6, 3)]
+
+
+@pytest.mark.parametrize("case", BF16_WGRAD_CASES, ids=[str(c) for c in BF16_WGRAD_CASES])
+def test_op_wgrad_bf16_is_exact_up_to_operand_rounding(lib, case):
+    """Every tile geometry of the bf16 weight-gradient kernel x split count {auto, 1, 3} against the float64
+    gradient computed from the bf16-ROUNDED x and dz (products of bf16 numbers are exact in fp32)."""
+    B, Cin, Cout, K, T, stride, pad, same = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31) + 17)
+    x = rng.uniform(-1, 1, (B, Cin, T)).astype(np.float32)
+    t_out = T if same else (T - K) // stride + 1
+    dz = rng.uniform(-1, 1, (B, Cout, t_out)).astype(np.float32)
+    xt = torch.tensor(_bf16_round(x))
+    dzr = _bf16_round(dz)
+    wtn = torch.zeros((K, Cin, Cout), dtype=torch.float64, requires_grad=True)
+    need = (t_out - 1) * stride + K - pad
+    y = F.conv1d(F.pad(xt, (pad, max(0, need - T))), wtn.permute(2, 1, 0), None, stride=stride)[:, :, :t_out]
+    (y * torch.tensor(dzr)).sum().backward()
+    ref_dw, ref_db = wtn.grad.numpy(), dzr.sum(axis=(0, 2))
+    sw, sb = max(1.0, np.abs(ref_dw).max()), max(1.0, np.abs(ref_db).max())
+    dxg, dzg = _cuda(x), _cuda(dz)
+    ran, worst = 0, 0.0
+    lib.wun_op_set_wgrad_bf16(1)
+    try:
+        for mtw, nw in WGRAD_GEOMS:
+            for ns in (0, 1, 3):
+                lib.wun_op_force_wgrad_variant(mtw, nw, ns)
+                scr = torch.empty(int(lib.wun_op_conv1d_wgrad_scratch(B, Cin, Cout, K, t_out)), device="cuda")
+                gdw = torch.full((K, Cin, Cout), float("nan"), device="cuda")
+                gdb = torch.full((Cout,), float("nan"), device="cuda")
+                rc = lib.wun_op_conv1d_wgrad(dxg.data_ptr(), dzg.data_ptr(), gdw.data_ptr(), gdb.data_ptr(), scr.data_ptr(),
+                                             B, Cin, Cout, K, T, t_out, stride, pad, _stream())
+                if rc == -2:
+                    continue
+                _lib.check(rc)
+                torch.cuda.synchronize()
+                ew = np.abs(gdw.cpu().numpy() - ref_dw).max() / sw
+                eb = np.abs(gdb.cpu().numpy() - ref_db).max() / sb
+                assert ew <= OP_TOL and eb <= OP_TOL, (mtw, nw, ns, ew, eb)
+                worst = max(worst, ew, eb)
+                ran += 1
+    finally:
+        lib.wun_op_force_wgrad_variant(0, 0, 0)
+        lib.wun_op_set_wgrad_bf16(0)
+    assert ran >= 6
+    record("op_wgrad_bf16_vs_rounded_operands", str(case), worst, OP_TOL)
+
+
 def _step(cfg_over, ocfg, params, B, frames, seed, tag, tune=False):
     sep = UnetAudioSeparator(wun.get_config("baseline", compute_dtype="bf16", **cfg_over), device="cuda:0")
     i, o = shapes.get_padding(ocfg, [B, frames, 0])

@@ -68,7 +68,7 @@ def test_tuning_table_export_import_roundtrip(tmp_path, monkeypatch):
     mix, targets = src()
     ta.tune(mix, targets)                                   # tunes and writes the table
     text = open(cache).read()
-    assert text.startswith("wun-tune 1 B=4 ") and "\ncf " in text and "\nwg " in text
+    assert text.startswith("wun-tune 2 order=") and " B=4 " in text and "\ncf " in text and "\nwg " in text and text.endswith("end\n")
     tb = training.Trainer(cfg)
     tb.tune(mix, targets)                                   # imports: no tuning pass
     assert tb.sep.tune_export() == text
@@ -79,3 +79,15 @@ def test_tuning_table_export_import_roundtrip(tmp_path, monkeypatch):
     other = training.Trainer(dict(cfg, num_frames=72))
     with pytest.raises(ValueError):
         other.sep.tune_import(text)
+    # a truncated table (lost tail) and an entry out of range are refused ...
+    with pytest.raises(ValueError):
+        tb.sep.tune_import(text[:len(text) // 2])
+    first_cf = next(l for l in text.splitlines() if l.startswith("cf "))
+    with pytest.raises(ValueError):
+        tb.sep.tune_import(text.replace(first_cf, "cf 9999 1", 1))
+    # ... and entries that are in range but not legal for their launch (split far past the scratch) are ignored
+    lines = text.splitlines()
+    forged = "\n".join([l if not l.startswith("cf ") else "cf 0 48" for l in lines]) + "\n"
+    tb.sep.tune_import(forged)                              # in range, but not legal choices for these launches:
+    lc = [float(tb.step(mix, targets).item()) for _ in range(2)]      # ignored at launch, heuristics used instead
+    assert all(np.isfinite(lc))

@@ -73,7 +73,14 @@ struct WgradArgs {
     int nsplit; int units_per_split; int nQT; int B;
     int ablate;      // debugging switches (only read when built with -DWUN_ABLATION)
     int force_mtw, force_nw;   // autotuner: geometry overrides (0 = heuristic)
+    int bf16;        // speed mode: operands rounded to bf16 in LDS, v_mfma_f32_16x16x32_bf16 (wun_wgrad_bf16.hip)
 };
+
+// tile geometry of a weight-gradient launch (shared by the exact-fp32 and the bf16 kernel: same tiles, same
+// tile-major partial layout, same split reduction)
+struct WgradGeom { int MTW, NW, nMG, nNG, TK, XP, ZP, nChMax, ONESP, XW4; size_t lds; };
+WgradGeom wgrad_geom(const WgradArgs& a);
+hipError_t launch_wgrad_bf16(const WgradArgs& a, hipStream_t s);
 
 // Narrow weight gradient (wun_narrow.hip): audio-input conv / output head.  Input = virtual concat of two
 // NCW sources as in WgradArgs; dz row n = (s, c), s = n / Nper, at dz + s*zss + b*dzbs + c*dzpitch.

@@ -1403,9 +1403,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradReduceArgs a) {
     }
 }
 
-struct WgradGeom { int MTW, NW, nMG, nNG, TK, XP, ZP, nChMax, ONESP, XW4; size_t lds; };
-
-static WgradGeom wgrad_geom(const WgradArgs& a) {
+WgradGeom wgrad_geom(const WgradArgs& a) {
     WgradGeom g;
     const int Ctot = a.C0 + a.C1;
     const int mtiles = (Ctot * a.KW + 1 + 15) / 16;
@@ -1495,6 +1493,7 @@ static hipError_t wgrad_launch_t(WgradArgs a, const WgradGeom& g, hipStream_t s)
 }
 
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
+    if (a.bf16) return launch_wgrad_bf16(a, s);
     // canonical layout required (the plan's buffers are; the single-op entry points repack)
     if ((a.pitch0 & 3) || (a.bs0 & 3) || (reinterpret_cast<uintptr_t>(a.src0) & 15) || a.pitch0 < 4) return hipErrorInvalidValue;
     if (a.C1 > 0 && ((a.pitch1 & 3) || (a.bs1 & 3) || (reinterpret_cast<uintptr_t>(a.src1) & 15) || a.pitch1 < 4)) return hipErrorInvalidValue;

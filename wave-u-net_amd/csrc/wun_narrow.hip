@@ -34,8 +34,10 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(NarrowWgradArgs a) {
     const int Ctot = a.C0 + a.C1;
     const int NP = Ctot * a.N;                              // (ci, n) pairs, <= 256
     float* Xs = nlds;                                       // [Ctot][XW]
-    float* Zs = Xs + Ctot * XW;                             // [N][TQ]
-    float* red = Zs + a.N * TQ;                             // [G][NP][KT + 1]
+    constexpr int ZP = TQ + 4;                              // dz row pitch: lanes of a wave read DIFFERENT rows at the same
+                                                            // column -- a pitch of 256 floats would put them all on one bank
+    float* Zs = Xs + Ctot * XW;                             // [N][ZP]
+    float* red = Zs + a.N * ZP;                             // [G][NP][KT + 1]
     const int tid = threadIdx.x;
     const int G = 256 / NP;                                 // lane groups per pair
     const bool live = tid < G * NP;
@@ -69,12 +71,12 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(NarrowWgradArgs a) {
         for (int i = tid; i < a.N * TQ; i += 256) {
             const int r = i / TQ, q = i - r * TQ;
             const int s = r / a.Nper, c = r - s * a.Nper;
-            Zs[i] = (q0 + q < a.Tq) ? a.dz[(long long)s * a.zss + (long long)b * a.dzbs + (long long)c * a.dzpitch + q0 + q] : 0.f;
+            Zs[r * ZP + q] = (q0 + q < a.Tq) ? a.dz[(long long)s * a.zss + (long long)b * a.dzbs + (long long)c * a.dzpitch + q0 + q] : 0.f;
         }
         __syncthreads();
         if (live) {
             const float* xr = Xs + ci * XW;
-            const float* zr = Zs + n * TQ;
+            const float* zr = Zs + n * ZP;
             for (int q4 = g; q4 < TQ / 4; q4 += G) {
                 const f32x4 z = *reinterpret_cast<const f32x4*>(zr + 4 * q4);
                 float xv[4 * XV];
@@ -147,7 +149,7 @@ size_t narrow_wgrad_lds(const NarrowWgradArgs& a) {
     const int XV = (3 * SI + KT + 3) / 4;
     const int XW = (WUN_NW_TQ * SI + KT - 1 + 4 * XV + 3) / 4 * 4;
     const int Ctot = a.C0 + a.C1, NP = Ctot * a.N, G = 256 / NP;
-    return sizeof(float) * ((size_t)Ctot * XW + (size_t)a.N * WUN_NW_TQ + (size_t)G * NP * (KT + 1));
+    return sizeof(float) * ((size_t)Ctot * XW + (size_t)a.N * (WUN_NW_TQ + 4) + (size_t)G * NP * (KT + 1));
 }
 
 int narrow_wgrad_units(const NarrowWgradArgs& a) { return a.B * ((a.Tq + WUN_NW_TQ - 1) / WUN_NW_TQ); }

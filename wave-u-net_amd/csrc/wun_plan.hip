@@ -734,6 +734,14 @@ static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const Conv
         int rcd = stream_dep(p, main, s);
         if (rcd) return rcd;
     }
+    // bf16 speed mode: operands rounded to bf16 in LDS (same tiles, same partial layout); launches with few
+    // positions are latency-bound and stay exact fp32
+    if (p->bf16 && parts[0].C0 + parts[0].C1 >= 8) {
+        long long rows = 0;
+        for (int i = 0; i < nparts; ++i) rows += (long long)parts[i].B * parts[i].Tq;
+        if (rows >= p->bf16_min_rows)
+            for (int i = 0; i < nparts; ++i) parts[i].bf16 = 1;
+    }
     // weight gradients alternate between two side streams; each has its own half of the partial buffer
     const long long pcap = p->partial_floats / 2;
     float* partial = ws + p->partial_off + ((p->side2 && s == p->side2) ? pcap : 0);
@@ -1218,6 +1226,7 @@ extern "C" int wun_adam_step(const wun_plan* p, float* params, const float* grad
 static const long long kOpScratchFloats = 8ll << 20;
 static int g_op_variant = -1, g_op_ksplit = 0;          // wun_op_force_conv_variant (test hook)
 static int g_op_wg_mtw = 0, g_op_wg_nw = 0, g_op_wg_nsplit = 0;   // wun_op_force_wgrad_variant (test hook)
+static int g_op_wg_bf16 = 0;                                       // wun_op_set_wgrad_bf16 (test hook)
 static float* op_scratch() {
     static float* buf = nullptr;
     if (!buf && hipMalloc((void**)&buf, kOpScratchFloats * sizeof(float)) != hipSuccess) {
@@ -1309,6 +1318,7 @@ extern "C" int wun_op_conv1d_wgrad(const float* x, const float* dz, float* dw, f
         if (m != g_op_wg_mtw || n != g_op_wg_nw)
             return fail(WUN_ERR_UNSUPPORTED, "forced weight-gradient tile geometry is not available for this shape");
     }
+    w.bf16 = g_op_wg_bf16;
     w.nsplit = wgrad_pick_nsplit(w);
     if (g_op_wg_nsplit > 0) {
         w.nsplit = std::min(g_op_wg_nsplit, wgrad_max_units(w));
@@ -1377,6 +1387,8 @@ extern "C" int wun_op_force_conv_variant(int variant, int ksplit) {
 }
 
 extern "C" int wun_op_num_conv_variants(void) { return conv_num_variants(); }
+
+extern "C" int wun_op_set_wgrad_bf16(int on) { g_op_wg_bf16 = on ? 1 : 0; return WUN_OK; }
 
 extern "C" int wun_op_force_wgrad_variant(int mtw, int nw, int nsplit) {
     g_op_wg_mtw = mtw; g_op_wg_nw = nw; g_op_wg_nsplit = nsplit;
