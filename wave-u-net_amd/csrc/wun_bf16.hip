@@ -30,12 +30,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ unsigned bf16_rne(float x) {
-    unsigned u = __float_as_uint(x);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return u >> 16;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// two fp32 -> packed bf16 pair, round-to-nearest-even: one v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){lo, hi}, bf16x2));
 }
-__device__ __forceinline__ unsigned pack2(float lo, float hi) { return bf16_rne(lo) | (bf16_rne(hi) << 16); }
 
 __device__ __forceinline__ int xcd_block(int bid, int grid) {
     const int per = grid >> 3, rem = grid & 7;
@@ -98,21 +98,25 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
         for (int n = 0; n < NW; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     float xreg[XIT][8];
-    const int nxitems = planes * ROWS * C8S;                // (channel group, plane, row) items per stage (<= XIT*256: launcher)
-
-    // stage-invariant state of the X items this thread stages, two registers per item:
-    //   xti[i] = clamped source time | channel group << 24 | time-valid << 28 | item-live << 29
-    //   xlo[i] = byte offset of the item's 16-byte slot in the LDS image
+    // X items: a 16-byte LDS slot = 8 channels of one (plane, row).  Item it = tid + i*256 is laid out as
+    // (channel group, position) with the positions of a group padded to a multiple of 64, so the channel
+    // group of an item is uniform across a wave: the 8 row pointers of a load batch are SCALAR values and a
+    // lane contributes only its 32-bit time offset (per-lane 64-bit address arithmetic was the dominant
+    // cost of a stage at bf16 MFMA rates).
+    const int PR = planes * ROWS;
+    const int PR64 = (PR + 63) & ~63;
+    const int nxitems = C8S * PR64;                         // <= XIT*256 (launcher)
+    // stage-invariant per-item state: xti[i] = clamped source time | time-valid << 28 | item-live << 29,
+    // (bits 24..27: the wave-uniform channel group), xlo[i] = byte offset of the slot in the LDS image
     int xti[XIT], xlo[XIT];
 #pragma unroll
     for (int i = 0; i < XIT; ++i) {
-        const int it = tid + i * 256;
-        const bool live = it < nxitems;
-        const int itc = live ? it : 0;
-        const int c8l = itc / (planes * ROWS);
-        const int pr = itc - c8l * (planes * ROWS);
-        const int pl = deint ? pr / ROWS : 0;
-        const int row = pr - pl * ROWS;
+        const int it0 = wave * 64 + i * 256;                // wave-uniform
+        const int c8l = it0 / PR64;
+        const int pr = it0 - c8l * PR64 + lane;
+        const bool live = it0 < nxitems && pr < PR;
+        const int pl = (deint && pr >= ROWS) ? 1 : 0;
+        const int row = live ? pr - pl * ROWS : 0;
         const int t = (deint ? 2 * (q0 + row) + pl : q0 + row) - a.shift;
         const bool tok = t >= 0 && t < a.Tin;
         const int tc = t < 0 ? 0 : (t > a.Tin - 1 ? a.Tin - 1 : t);          // Tin < 2^24 (checked by the launcher)
@@ -125,8 +129,8 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
 #pragma unroll
         for (int i = 0; i < XIT; ++i) {
             if (i * 256 < nxitems) {                         // uniform
-                const int t = xti[i] & 0xFFFFFF;
-                const int cbase = st * CKW + ((xti[i] >> 24) & 15) * 8;
+                const unsigned t = (unsigned)(xti[i] & 0xFFFFFF);
+                const int cbase = st * CKW + __builtin_amdgcn_readfirstlane((xti[i] >> 24) & 15) * 8;     // wave-uniform
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     int c = cbase + e;
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
         for (int i = 0; i < XIT; ++i) {
             if (i * 256 < nxitems && ((xti[i] >> 29) & 1)) {
                 const bool tok = (xti[i] >> 28) & 1;
-                const int cbase = st * CKW + ((xti[i] >> 24) & 15) * 8;
+                const int cbase = st * CKW + __builtin_amdgcn_readfirstlane((xti[i] >> 24) & 15) * 8;
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (tok && cbase + e < Ctot) ? xreg[i][e] : 0.f;
@@ -154,18 +158,23 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
     };
     // ---- W: packed bf16 image [KW][C8p][Npad][8] -> LDS [tap][channel group][cout][8], 16 bytes per lane ----
     const unsigned short* Wb = reinterpret_cast<const unsigned short*>(a.W);
+    const int per_tap = C8S * NT;                           // 16-byte items per tap (<= 768)
+    int wofs[3];                                            // tap-invariant element offset of this lane's items
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int r = k * 256 + tid;
+        const int c8l = r / NT, n = r - c8l * NT;           // NT is a compile-time constant: no integer division
+        wofs[k] = r < per_tap ? (c8l * a.wb_npad + n) * 8 : -1;
+    }
     auto dma_w = [&](int st, int buf) {
         unsigned char* wbuf = Ws + buf * wbytes;
-        const int per_tap = C8S * NT;                           // 16-byte items per tap
         for (int j = 0; j < KW; ++j) {
             const unsigned short* wj = Wb + (((long long)j * a.wb_c8p + st * C8S) * a.wb_npad + n0) * 8;
-            for (int i0 = 0; i0 < per_tap; i0 += 256) {
-                const int r = i0 + tid;
-                if (r < per_tap) {
-                    const int c8l = r / NT, n = r - c8l * NT;   // NT is a compile-time constant: no integer division
-                    __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(wj + ((long long)c8l * a.wb_npad + n) * 8),
-                                                     (lds_void_t*)(wbuf + (j * per_tap + i0 + wave * 64) * 16), 16, 0, 0);
-                }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (k * 256 < per_tap && wofs[k] >= 0)
+                    __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(wj + wofs[k]),
+                                                     (lds_void_t*)(wbuf + (j * per_tap + k * 256 + wave * 64) * 16), 16, 0, 0);
             }
         }
     };
@@ -318,7 +327,7 @@ static int bf16_pick_nck(const ConvArgs& a, int TT, int NT, int xit) {
     if (nck > 3) nck = 3;
     const int maxck = (a.C0 + a.C1 + 31) / 32;
     if (nck > maxck) nck = maxck;
-    while (nck > 1 && (planes * bf16_rows(a, TT) * 4 * nck > xit * 256 || bf16_lds(a, TT, NT, nck) > 160 * 1024)) --nck;
+    while (nck > 1 && (((planes * bf16_rows(a, TT) + 63) & ~63) * 4 * nck > xit * 256 || bf16_lds(a, TT, NT, nck) > 160 * 1024)) --nck;
     return nck;
 }
 
@@ -329,7 +338,7 @@ static hipError_t conv_bf16_launch_t(ConvArgs a, hipStream_t s) {
     const int ROWS = bf16_rows(a, TT);
     const int planes = a.loader == LOADER_DEINT ? 2 : 1;
     const size_t lds = bf16_lds(a, TT, NT, NCK);
-    if (lds > 160 * 1024 || planes * ROWS * 4 * NCK > BfXit<MT>::v * 256) return hipErrorInvalidValue;
+    if (lds > 160 * 1024 || ((planes * ROWS + 63) & ~63) * 4 * NCK > BfXit<MT>::v * 256) return hipErrorInvalidValue;
     const int nTT = (a.Tout + TT - 1) / TT, nNT = (a.N + NT - 1) / NT;
     auto kern = conv_bf16_kernel<MT, NW>;
     static size_t lds_allowed = 64 * 1024;

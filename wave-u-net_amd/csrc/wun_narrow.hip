@@ -58,20 +58,49 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(NarrowWgradArgs a) {
         const int q0 = qt * TQ;
         const int t0 = q0 * SI - a.shift;
         __syncthreads();
-        // ---- stage: input rows (zero outside [0, Tin)), dz rows (zero beyond Tq) ----
-        for (int i = tid; i < Ctot * XW; i += 256) {
-            const int c = i / XW, x = i - c * XW;
-            const int t = t0 + x;
-            float v = 0.f;
-            if (t >= 0 && t < a.Tin)
-                v = c < a.C0 ? a.src0[(long long)b * a.bs0 + (long long)c * a.pitch0 + a.off0 + t]
-                             : a.src1[(long long)b * a.bs1 + (long long)(c - a.C0) * a.pitch1 + a.off1 + t];
-            Xs[i] = v;
+        // ---- stage: input rows (zero outside [0, Tin)), dz rows (zero beyond Tq).  All global loads of a
+        // batch are issued before the first LDS write, so a unit costs one memory round trip, not one per element;
+        // dz rows are read as 16-byte vectors (row pitch and q0 are multiples of 4) ----
+        for (int i0 = 0; i0 < Ctot * XW; i0 += 8 * 256) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int i = i0 + e * 256 + tid;
+                const int c = i / XW, x = i - c * XW;
+                const int t = t0 + x;
+                v[e] = 0.f;
+                if (i < Ctot * XW && t >= 0 && t < a.Tin)
+                    v[e] = c < a.C0 ? a.src0[(long long)b * a.bs0 + (long long)c * a.pitch0 + a.off0 + t]
+                                    : a.src1[(long long)b * a.bs1 + (long long)(c - a.C0) * a.pitch1 + a.off1 + t];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int i = i0 + e * 256 + tid;
+                if (i < Ctot * XW) Xs[i] = v[e];
+            }
         }
-        for (int i = tid; i < a.N * TQ; i += 256) {
-            const int r = i / TQ, q = i - r * TQ;
-            const int s = r / a.Nper, c = r - s * a.Nper;
-            Zs[r * ZP + q] = (q0 + q < a.Tq) ? a.dz[(long long)s * a.zss + (long long)b * a.dzbs + (long long)c * a.dzpitch + q0 + q] : 0.f;
+        for (int i0 = 0; i0 < a.N * (TQ / 4); i0 += 8 * 256) {
+            f32x4 v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int i = i0 + e * 256 + tid;
+                const int r = i / (TQ / 4), q = (i - r * (TQ / 4)) * 4;
+                const int s = r / a.Nper, c = r - s * a.Nper;
+                v[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (i < a.N * (TQ / 4) && q0 + q < a.Tq) {
+                    const float* zp = a.dz + (long long)s * a.zss + (long long)b * a.dzbs + (long long)c * a.dzpitch + q0 + q;
+                    if (q0 + q + 3 < a.dzpitch) v[e] = *reinterpret_cast<const f32x4*>(zp);
+                    else for (int k = 0; k < 4; ++k) if (q0 + q + k < a.Tq) v[e][k] = zp[k];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (q0 + q + k >= a.Tq) v[e][k] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int i = i0 + e * 256 + tid;
+                const int r = i / (TQ / 4), q = (i - r * (TQ / 4)) * 4;
+                if (i < a.N * (TQ / 4)) *reinterpret_cast<f32x4*>(&Zs[r * ZP + q]) = v[e];
+            }
         }
         __syncthreads();
         if (live) {
@@ -139,6 +168,8 @@ bool narrow_wgrad_supported(const NarrowWgradArgs& a) {
     if (a.stride != 1 && a.stride != 2) return false;
     if (a.stride == 2 && a.KW > 15) return false;
     if (a.N / a.Nper > 4 || a.N % a.Nper != 0) return false;
+    // dz rows are read as 16-byte vectors
+    if ((a.dzpitch & 3) || (a.dzbs & 3) || (a.zss & 3) || (reinterpret_cast<uintptr_t>(a.dz) & 15)) return false;
     return true;
 }
 

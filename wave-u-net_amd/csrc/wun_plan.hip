@@ -938,7 +938,7 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
         nw.Tin = p->t_feat; nw.shift = h.padl; nw.KW = Ko; nw.stride = 1;
         nw.dz = h.dpre; nw.zss = h.dps; nw.dzbs = h.dpbs; nw.dzpitch = h.dppitch;
         nw.N = p->Sh * C; nw.Nper = C; nw.Tq = p->Tout; nw.B = p->B;
-        if (narrow_wgrad_supported(nw)) {
+        if (narrow_wgrad_supported(nw) && getenv("WUN_NO_NARROW") == nullptr) {
             long long woff[4] = {0, 0, 0, 0}, boff[4] = {0, 0, 0, 0};
             for (int sh = 0; sh < p->Sh; ++sh) { woff[sh] = p->head[sh].woff; boff[sh] = p->head[sh].boff; }
             if ((rc = run_narrow_wgrad(p, &nw, 1, woff, boff, ws, grads, s, wstream()))) return rc;
@@ -1038,7 +1038,7 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
                 nw[1].Tin = d.tc + Kd - 1; nw[1].shift = 0; nw[1].stride = 1; nw[1].off0 = d.cs;
                 nw[1].dz = ws + p->dz_skip[0].off; nw[1].dzbs = p->dz_skip[0].bs; nw[1].dzpitch = p->dz_skip[0].pitch; nw[1].Tq = d.tc;
             }
-            narrow = narrow_wgrad_supported(nw[0]) && (same || narrow_wgrad_supported(nw[1]));
+            narrow = narrow_wgrad_supported(nw[0]) && (same || narrow_wgrad_supported(nw[1])) && getenv("WUN_NO_NARROW") == nullptr;
         }
         if (narrow) {
             const long long woff[4] = {cl.woff, 0, 0, 0}, boff[4] = {cl.boff, 0, 0, 0};

@@ -25,12 +25,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ unsigned wb_rne(float x) {
-    unsigned u = __float_as_uint(x);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return u >> 16;
+typedef __bf16 wb_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float wb_f32x2 __attribute__((ext_vector_type(2)));
+// two fp32 -> packed bf16 pair, round-to-nearest-even: one v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned wb_pack2(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((wb_f32x2){lo, hi}, wb_bf16x2));
 }
-__device__ __forceinline__ unsigned wb_pack2(float lo, float hi) { return wb_rne(lo) | (wb_rne(hi) << 16); }
 
 __device__ __forceinline__ int wb_xcd_block(int bid, int grid) {
     const int per = grid >> 3, rem = grid & 7;
