@@ -17,6 +17,7 @@
 #include "wun_internal.h"
 
 #include <cstdio>
+#include <cstdlib>
 
 namespace wun {
 
@@ -189,7 +190,9 @@ long long narrow_wgrad_partial_floats(const NarrowWgradArgs& a) { return (long l
 
 int narrow_wgrad_pick_nsplit(const NarrowWgradArgs& a) {
     const int units = narrow_wgrad_units(a);
-    int ns = units < 1024 ? units : 1024;                   // ~4 workgroups per CU, each streaming >= 1 unit
+    int cap = 1024;                                         // ~4 workgroups per CU, each streaming >= 1 unit
+    if (const char* e = getenv("WUN_NARROW_SPLITS")) cap = atoi(e);
+    int ns = units < cap ? units : cap;
     return ns < 1 ? 1 : ns;
 }
 
