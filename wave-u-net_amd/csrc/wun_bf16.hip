@@ -23,6 +23,7 @@
 #include "wun_internal.h"
 
 #include <cstdio>
+#include <cstdlib>
 
 namespace wun {
 
@@ -52,11 +53,21 @@ typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
 template <int MT> struct BfXit { static constexpr int v = MT == 4 ? 9 : (MT == 2 ? 7 : 4); };
 
 // Stage = NCK chunks of 32 input channels x ALL taps (so a stage carries enough MFMAs -- ~12 tap-chunks --
-// to cover a global-memory round trip).  Weights of stage s+1 go global -> LDS directly
-// (global_load_lds, 16 bytes per lane: no registers, the image is already in LDS order); the input window
-// of stage s+1 is fetched into registers while stage s computes and written (bf16-rounded) afterwards.
-template <int MT, int NW>
-__global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int nNT, int NCK, int ROWS) {
+// to cover a global-memory round trip).  Weights go global -> LDS directly (global_load_lds, 16 bytes per
+// lane: no registers, the image is already in LDS order); the input window is fetched into registers while
+// the previous MFMAs run and written (bf16-rounded) afterwards.
+//
+// Two schedules, chosen by the launcher:
+//   * S > 1 stages (wide layers): one output tile per workgroup; weights and input of stage s+1 stream in
+//     while stage s computes (both double-buffered);
+//   * S == 1 (all input channels fit one stage -- the shallow, long layers that carry most of the FLOPs and
+//     all of the HBM traffic): WEIGHTS-STATIONARY.  A workgroup loads its column tile's weights once and
+//     walks `tpw` consecutive time tiles; the input window of tile i+1 streams in (double-buffered) while
+//     tile i computes and stores, so a tile costs its MFMAs, not a dependent chain of memory round trips.
+template <int MT, int NW, bool WS>
+__global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int nNT, int NCK, int ROWS, int tpw_arg) {
+    const int tpw = WS ? tpw_arg : 1;                       // WS: weights-stationary walk over tpw time tiles (own instantiation:
+                                                            // the one-tile kernel must not pay its registers)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int WT = 4;
     constexpr int TT = WT * MT * 16;
@@ -67,36 +78,30 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
     const int KW = a.KW;
     const int XPB = 64 * NCK + 32;                          // bytes per X row: conflict-free for ds_read_b128 at every tap
     const int C8S = 4 * NCK;                                // 8-channel groups per stage
+    const int Ctot = a.C0 + a.C1;
+    const int CKW = 32 * NCK;
+    const int S = (Ctot + CKW - 1) / CKW;
 
     const int xbytes = planes * ROWS * XPB;
     const int wbytes = KW * C8S * NT * 16;
-    const int nbuf = (a.C0 + a.C1 + 32 * NCK - 1) / (32 * NCK) > 1 ? 2 : 1;   // one stage: nothing to double-buffer
-    unsigned char* Xs = smem;                               // nbuf X buffers, then nbuf W buffers
-    unsigned char* Ws = smem + nbuf * xbytes;
+    const int nxb = (S > 1 || tpw > 1) ? 2 : 1;             // X buffers; W buffers: 2 only when there are several stages
+    unsigned char* Xs = smem;
+    unsigned char* Ws = smem + nxb * xbytes;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int li = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bid = xcd_block((int)blockIdx.x, (int)gridDim.x);
-    const int nt = bid % nNT; bid /= nNT;
-    const int tt = bid % nTT; bid /= nTT;
-    const int b = bid;
-    const int q0 = tt * TT, n0 = nt * NT;
+    const int nt = bid % nNT;
+    const int seg = bid / nNT;
+    const int n0 = nt * NT;
     const int wt0 = wave * MT * 16;
-    const int Ctot = a.C0 + a.C1;
-    const int CKW = 32 * NCK;
-    const int S = (Ctot + CKW - 1) / CKW;
-
-    const float* src0b = a.src0 + (long long)b * a.bs0 + a.off0;
-    const float* src1b = (a.src1 != nullptr) ? a.src1 + (long long)b * a.bs1 + a.off1 : src0b;
+    const int tix0 = seg * tpw;
+    int tix1 = tix0 + tpw;
+    if (tix1 > a.B * nTT) tix1 = a.B * nTT;
 
     f32x4 acc[MT][NW];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NW; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
     float xreg[XIT][8];
     // X items: a 16-byte LDS slot = 8 channels of one (plane, row).  Item it = tid + i*256 is laid out as
     // (channel group, position) with the positions of a group padded to a multiple of 64, so the channel
@@ -106,9 +111,10 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
     const int PR = planes * ROWS;
     const int PR64 = (PR + 63) & ~63;
     const int nxitems = C8S * PR64;                         // <= XIT*256 (launcher)
-    // stage-invariant per-item state: xti[i] = clamped source time | time-valid << 28 | item-live << 29,
-    // (bits 24..27: the wave-uniform channel group), xlo[i] = byte offset of the slot in the LDS image
-    int xti[XIT], xlo[XIT];
+    // tile-invariant per-item state: xfl[i] = (source time relative to the tile start + 64) | channel group << 24
+    // | item-live << 29; xlo[i] = byte offset of the slot in the LDS image.  Per tile: xti[i] = clamped source
+    // time | time-valid << 28.
+    int xfl[XIT], xlo[XIT], xti[XIT];
 #pragma unroll
     for (int i = 0; i < XIT; ++i) {
         const int it0 = wave * 64 + i * 256;                // wave-uniform
@@ -117,12 +123,25 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
         const bool live = it0 < nxitems && pr < PR;
         const int pl = (deint && pr >= ROWS) ? 1 : 0;
         const int row = live ? pr - pl * ROWS : 0;
-        const int t = (deint ? 2 * (q0 + row) + pl : q0 + row) - a.shift;
-        const bool tok = t >= 0 && t < a.Tin;
-        const int tc = t < 0 ? 0 : (t > a.Tin - 1 ? a.Tin - 1 : t);          // Tin < 2^24 (checked by the launcher)
-        xti[i] = tc | (c8l << 24) | ((tok ? 1 : 0) << 28) | ((live ? 1 : 0) << 29);
+        const int tr = (deint ? 2 * row + pl : row) - a.shift + 64;      // >= 0: shift <= 14
+        xfl[i] = tr | (c8l << 24) | ((live ? 1 : 0) << 29);
         xlo[i] = (pl * ROWS + row) * XPB + c8l * 16;
     }
+    const float* src0b = a.src0;
+    const float* src1b = a.src0;
+    auto set_tile = [&](int tix, int& b, int& q0) {
+        b = tix / nTT;
+        q0 = (tix - b * nTT) * TT;
+        src0b = a.src0 + (long long)b * a.bs0 + a.off0;
+        src1b = (a.src1 != nullptr) ? a.src1 + (long long)b * a.bs1 + a.off1 : src0b;
+        const int tq = (deint ? 2 * q0 : q0) - 64;
+#pragma unroll
+        for (int i = 0; i < XIT; ++i) {
+            const int t = (xfl[i] & 0xFFFFFF) + tq;
+            const int tc = t < 0 ? 0 : (t > a.Tin - 1 ? a.Tin - 1 : t);      // Tin < 2^24 (checked by the launcher)
+            xti[i] = tc | ((t >= 0 && t < a.Tin ? 1 : 0) << 28);
+        }
+    };
 
     // ---- X: global -> registers, registers -> LDS (bf16, zero fill) ----
     auto load_x = [&](int st) {
@@ -130,7 +149,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
         for (int i = 0; i < XIT; ++i) {
             if (i * 256 < nxitems) {                         // uniform
                 const unsigned t = (unsigned)(xti[i] & 0xFFFFFF);
-                const int cbase = st * CKW + __builtin_amdgcn_readfirstlane((xti[i] >> 24) & 15) * 8;     // wave-uniform
+                const int cbase = st * CKW + __builtin_amdgcn_readfirstlane((xfl[i] >> 24) & 15) * 8;     // wave-uniform
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     int c = cbase + e;
@@ -145,9 +164,9 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
         unsigned char* xb = Xs + buf * xbytes;
 #pragma unroll
         for (int i = 0; i < XIT; ++i) {
-            if (i * 256 < nxitems && ((xti[i] >> 29) & 1)) {
+            if (i * 256 < nxitems && ((xfl[i] >> 29) & 1)) {
                 const bool tok = (xti[i] >> 28) & 1;
-                const int cbase = st * CKW + __builtin_amdgcn_readfirstlane((xti[i] >> 24) & 15) * 8;
+                const int cbase = st * CKW + __builtin_amdgcn_readfirstlane((xfl[i] >> 24) & 15) * 8;
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (tok && cbase + e < Ctot) ? xreg[i][e] : 0.f;
@@ -181,9 +200,9 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
 
     // ---- MFMA over all (tap, channel sub-chunk) k-steps of one stage; the operands of k-step i+1 are read from
     // LDS before the MFMAs of k-step i issue (two register sets), so LDS latency hides behind the matrix pipe ----
-    auto run_stage = [&](int st) {
-        const unsigned char* xb = Xs + (st & 1) * xbytes + (wt0 + li) * XPB + lg * 16;
-        const unsigned char* wbuf = Ws + (st & 1) * wbytes + (lg * NT + li) * 16;
+    auto run_stage = [&](int xbuf, int wbufi) {
+        const unsigned char* xb = Xs + xbuf * xbytes + (wt0 + li) * XPB + lg * 16;
+        const unsigned char* wbuf = Ws + wbufi * wbytes + (lg * NT + li) * 16;
         const int nsteps = KW * NCK;
         auto ldops = [&](int j, int sc, bf16x8 (&av)[MT], bf16x8 (&bv)[NW]) {
             const int pl = deint ? (j & 1) : 0;
@@ -216,76 +235,126 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
         }
     };
 
-    // ---- pipeline: one barrier per stage ----
+    // ---- epilogue of one tile (fp32; same arithmetic as the exact-fp32 kernel's).  Every launch argument it needs
+    // is read into a local first: selecting between `a.dst0` and `a.dst1` per lane otherwise compiles to a VECTOR load
+    // of the kernel-argument segment followed by s_waitcnt vmcnt(0) -- which also drains the input prefetch of the next
+    // tile and serialises the whole pipeline (measured: phases became exactly additive) ----
+    const bool lrelu = (a.flags & F_LRELU) != 0;
+    const bool accum = (a.flags & F_ACCUM) != 0;
+    const bool vec = (a.flags & F_VEC4) != 0;
+    float* const e_dst0 = a.dst0; float* const e_dst1 = a.dst1;
+    const float* const e_msk0 = a.msk0; const float* const e_msk1 = a.msk1;
+    const float* const e_bias = a.bias;
+    float* const e_dec = a.dec;
+    const long long e_obs0 = a.obs0, e_obs1 = a.obs1, e_decbs = a.decbs;
+    const int e_op0 = a.opitch0, e_op1 = a.opitch1, e_oo0 = a.ooff0, e_oo1 = a.ooff1, e_N = a.N, e_N0 = a.N0,
+              e_Tout = a.Tout, e_os = a.ostride, e_decp = a.decpitch;
+    float e_bv[NW];                                         // this lane's bias values, loaded once (a load inside the
+#pragma unroll                                              // tile loop would wait on vmcnt(0) and drain the input prefetch)
+    for (int n = 0; n < NW; ++n) {
+        const int ncol = n0 + n * 16 + li;
+        e_bv[n] = (e_bias != nullptr && ncol < e_N) ? e_bias[ncol] : 0.f;
+    }
+    auto epilogue = [&](int b, int q0) {
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            const int ncol = n0 + n * 16 + li;
+            if (ncol >= e_N) continue;
+            const float bvv = e_bv[n];
+            const bool first = ncol < e_N0;
+            float* const dst = first ? e_dst0 : e_dst1;
+            const float* const msk = first ? e_msk0 : e_msk1;
+            const long long rowbase = first ? (long long)b * e_obs0 + (long long)ncol * e_op0 + e_oo0
+                                            : (long long)b * e_obs1 + (long long)(ncol - e_N0) * e_op1 + e_oo1;
+            float* decrow = (e_dec != nullptr && first) ? e_dec + (long long)b * e_decbs + (long long)ncol * e_decp : nullptr;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int q = q0 + wt0 + m * 16 + lg * 4;
+                if (vec && q + 3 < e_Tout) {
+                    f32x4 v = acc[m][n];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] += bvv;
+                        if (lrelu) v[r] = fmaxf(0.2f * v[r], v[r]);
+                    }
+                    const long long idx = rowbase + q;
+                    if (msk != nullptr) {
+                        const f32x4 mk = *reinterpret_cast<const f32x4*>(&msk[idx]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] *= (mk[r] > 0.f) ? 1.f : 0.2f;
+                    }
+                    if (accum) v += *reinterpret_cast<const f32x4*>(&dst[idx]);
+                    *reinterpret_cast<f32x4*>(&dst[idx]) = v;
+                    if (decrow != nullptr) {
+                        decrow[q >> 1] = v[0];
+                        decrow[(q >> 1) + 1] = v[2];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (q + r < e_Tout) {
+                            float v = acc[m][n][r] + bvv;
+                            if (lrelu) v = fmaxf(0.2f * v, v);
+                            const long long idx = rowbase + (long long)(q + r) * e_os;
+                            if (msk != nullptr) v *= (msk[idx] > 0.f) ? 1.f : 0.2f;
+                            if (accum) v += dst[idx];
+                            dst[idx] = v;
+                            if (decrow != nullptr && ((q + r) & 1) == 0) decrow[(q + r) >> 1] = v;
+                        }
+                    }
+                }
+            }
+        }
+    };
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NW; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+
+    // One loop serves both schedules (single call site per phase keeps the code and register footprint small):
+    //   S > 1 : tpw == 1, the inner stage loop double-buffers weights + input window;
+    //   S == 1: weights stay, the tile loop double-buffers the input window of the next tile.
+    int b, q0;
+    set_tile(tix0, b, q0);
     dma_w(0, 0);
     load_x(0);
     store_x(0, 0);
     __syncthreads();
-    for (int st = 0; st < S; ++st) {
-        const bool has_next = st + 1 < S;
-        if (has_next) {
-            dma_w(st + 1, (st + 1) & 1);
-            load_x(st + 1);
+    if constexpr (!WS) {
+        // ---- one output tile: weights and input window of stage st+1 stream in under the MFMAs of stage st ----
+        zero_acc();
+        for (int st = 0; st < S; ++st) {
+            const bool has_next = st + 1 < S;
+            if (has_next) {
+                dma_w(st + 1, (st + 1) & 1);
+                load_x(st + 1);
+            }
+            run_stage(st & 1, st & 1);
+            if (has_next) {
+                store_x(st + 1, (st + 1) & 1);
+                __syncthreads();
+            }
         }
-        run_stage(st);
-        if (has_next) store_x(st + 1, (st + 1) & 1);
-        __syncthreads();
-    }
-
-    // ---- epilogue (fp32; same as the exact-fp32 kernel's) ----
-    const bool lrelu = (a.flags & F_LRELU) != 0;
-    const bool accum = (a.flags & F_ACCUM) != 0;
-    const bool vec = (a.flags & F_VEC4) != 0;
-#pragma unroll
-    for (int n = 0; n < NW; ++n) {
-        const int ncol = n0 + n * 16 + li;
-        if (ncol >= a.N) continue;
-        const float bvv = (a.bias != nullptr) ? a.bias[ncol] : 0.f;
-        float* dst; const float* msk; long long rowbase;
-        if (ncol < a.N0) {
-            rowbase = (long long)b * a.obs0 + (long long)ncol * a.opitch0 + a.ooff0;
-            dst = a.dst0; msk = a.msk0;
-        } else {
-            rowbase = (long long)b * a.obs1 + (long long)(ncol - a.N0) * a.opitch1 + a.ooff1;
-            dst = a.dst1; msk = a.msk1;
-        }
-        float* decrow = (a.dec != nullptr && ncol < a.N0)
-                            ? a.dec + (long long)b * a.decbs + (long long)ncol * a.decpitch : nullptr;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int q = q0 + wt0 + m * 16 + lg * 4;
-            if (vec && q + 3 < a.Tout) {
-                f32x4 v = acc[m][n];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] += bvv;
-                    if (lrelu) v[r] = fmaxf(0.2f * v[r], v[r]);
-                }
-                const long long idx = rowbase + q;
-                if (msk != nullptr) {
-                    const f32x4 mk = *reinterpret_cast<const f32x4*>(&msk[idx]);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] *= (mk[r] > 0.f) ? 1.f : 0.2f;
-                }
-                if (accum) v += *reinterpret_cast<const f32x4*>(&dst[idx]);
-                *reinterpret_cast<f32x4*>(&dst[idx]) = v;
-                if (decrow != nullptr) {
-                    decrow[q >> 1] = v[0];
-                    decrow[(q >> 1) + 1] = v[2];
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (q + r < a.Tout) {
-                        float v = acc[m][n][r] + bvv;
-                        if (lrelu) v = fmaxf(0.2f * v, v);
-                        const long long idx = rowbase + (long long)(q + r) * a.ostride;
-                        if (msk != nullptr) v *= (msk[idx] > 0.f) ? 1.f : 0.2f;
-                        if (accum) v += dst[idx];
-                        dst[idx] = v;
-                        if (decrow != nullptr && ((q + r) & 1) == 0) decrow[(q + r) >> 1] = v;
-                    }
-                }
+        epilogue(b, q0);
+    } else {
+        // ---- weights-stationary (S == 1): walk this workgroup's time tiles, input window double-buffered ----
+        int xb = 0;
+        for (int tix = tix0; tix < tix1; ++tix) {
+            const int bc = b, qc = q0;
+            const bool next_tile = tix + 1 < tix1;
+            zero_acc();
+            if (next_tile) {
+                set_tile(tix + 1, b, q0);
+                if (!(a.flags & 0x40000)) load_x(0);
+            }
+            if (!(a.flags & 0x10000)) run_stage(xb, 0);
+            if (!(a.flags & 0x20000)) epilogue(bc, qc);
+            if (next_tile) {
+                store_x(0, xb ^ 1);
+                __syncthreads();
+                xb ^= 1;
             }
         }
     }
@@ -298,13 +367,13 @@ bool conv_bf16_supported(const ConvArgs& a) {
     if (a.flags & F_PHASE2) return false;
     if (a.C0 + a.C1 < 8) return false;                    // the 1-/2-channel audio input stays on the exact-fp32 kernel
     if (a.KW < 1 || a.KW > WUN_BF_KMAX) return false;
-    if (a.Tin >= (1 << 24)) return false;
+    if (a.Tin >= (1 << 23)) return false;
     return true;
 }
 
 // Few output positions: the launch is latency-bound, not matrix-pipe-bound, and the exact-fp32 kernels
-// (batch-folded tiles, split-K) serve it at least as fast -- those levels keep exact arithmetic in the
-// speed mode.  min_rows: the plan's threshold on B * Tout (WUN_BF16_MIN_ROWS, default 16384).
+// (batch-folded tiles, split-K) can serve it as well -- a plan may keep such levels on exact arithmetic.
+// min_rows: the plan's threshold on B * Tout (WUN_BF16_MIN_ROWS).
 bool conv_bf16_preferred(const ConvArgs& a, long long min_rows) {
     return conv_bf16_supported(a) && (long long)a.B * a.Tout >= min_rows;
 }
@@ -314,20 +383,42 @@ static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) 
 static inline int bf16_rows(const ConvArgs& a, int TT) {
     return a.loader == LOADER_DEINT ? TT + (a.KW + 1) / 2 : TT + a.KW - 1;
 }
+// tiles per workgroup in the weights-stationary schedule (one stage): enough workgroups for two rounds on 256 CUs
+static inline int bf16_tpw(const ConvArgs& a, int TT, int NT, int nck) {
+    const int S = (a.C0 + a.C1 + 32 * nck - 1) / (32 * nck);
+    if (S > 1) return 1;
+    // the tile walk only pays when the epilogue issues no loads (no mask / accumulate: forward convs) -- a load there
+    // waits on vmcnt(0) and drains the next tile's input prefetch
+    if (a.msk0 != nullptr || a.msk1 != nullptr || (a.flags & F_ACCUM)) return 1;
+    static const int enable = getenv("WUN_BF16_STATIONARY") ? atoi(getenv("WUN_BF16_STATIONARY")) : 0;
+    if (!enable) return 1;
+    const long long jobs = (long long)((a.Tout + TT - 1) / TT) * a.B;          // time tiles per column tile
+    const long long cols = (a.N + NT - 1) / NT;
+    long long tpw = (jobs * cols + 511) / 512;
+    if (tpw < 1) tpw = 1;
+    if (tpw > 64) tpw = 64;
+    return (int)tpw;
+}
 static inline size_t bf16_lds(const ConvArgs& a, int TT, int NT, int nck) {
     const int planes = a.loader == LOADER_DEINT ? 2 : 1;
-    const int nbuf = (a.C0 + a.C1 + 32 * nck - 1) / (32 * nck) > 1 ? 2 : 1;
-    return nbuf * ((size_t)planes * bf16_rows(a, TT) * (64 * nck + 32) + (size_t)a.KW * 4 * nck * NT * 16);
+    const int S = (a.C0 + a.C1 + 32 * nck - 1) / (32 * nck);
+    const int nxb = (S > 1 || bf16_tpw(a, TT, NT, nck) > 1) ? 2 : 1, nwb = S > 1 ? 2 : 1;
+    return nxb * ((size_t)planes * bf16_rows(a, TT) * (64 * nck + 32)) + nwb * ((size_t)a.KW * 4 * nck * NT * 16);
 }
 // channel chunks per stage: enough tap-chunks (~12) per stage to cover a memory round trip, within the
 // X-staging register budget and 160 KiB of LDS
 static int bf16_pick_nck(const ConvArgs& a, int TT, int NT, int xit) {
     const int planes = a.loader == LOADER_DEINT ? 2 : 1;
+    const int maxck = (a.C0 + a.C1 + 31) / 32;
+    auto fits = [&](int nck) {
+        return ((planes * bf16_rows(a, TT) + 63) & ~63) * 4 * nck <= xit * 256 && bf16_lds(a, TT, NT, nck) <= 160 * 1024;
+    };
+    // all input channels in one stage -> weights-stationary schedule
+    if (maxck <= 3 && fits(maxck)) return maxck;
     int nck = (12 + a.KW - 1) / a.KW;
     if (nck > 3) nck = 3;
-    const int maxck = (a.C0 + a.C1 + 31) / 32;
     if (nck > maxck) nck = maxck;
-    while (nck > 1 && (((planes * bf16_rows(a, TT) + 63) & ~63) * 4 * nck > xit * 256 || bf16_lds(a, TT, NT, nck) > 160 * 1024)) --nck;
+    while (nck > 1 && !fits(nck)) --nck;
     return nck;
 }
 
@@ -340,21 +431,23 @@ static hipError_t conv_bf16_launch_t(ConvArgs a, hipStream_t s) {
     const size_t lds = bf16_lds(a, TT, NT, NCK);
     if (lds > 160 * 1024 || ((planes * ROWS + 63) & ~63) * 4 * NCK > BfXit<MT>::v * 256) return hipErrorInvalidValue;
     const int nTT = (a.Tout + TT - 1) / TT, nNT = (a.N + NT - 1) / NT;
-    auto kern = conv_bf16_kernel<MT, NW>;
-    static size_t lds_allowed = 64 * 1024;
-    if (lds > lds_allowed) {
+    const int tpw = bf16_tpw(a, TT, NT, NCK);
+    auto kern = tpw > 1 ? conv_bf16_kernel<MT, NW, true> : conv_bf16_kernel<MT, NW, false>;
+    static size_t lds_allowed[2] = {64 * 1024, 64 * 1024};
+    if (lds > lds_allowed[tpw > 1]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        lds_allowed = lds;
+        lds_allowed[tpw > 1] = lds;
     }
-    const long long grid = (long long)nTT * nNT * a.B;
+    const long long nseg = ((long long)nTT * a.B + tpw - 1) / tpw;
+    const long long grid = nseg * nNT;
     if (grid <= 0) return hipSuccess;
     char nm[64], tag[160];
-    snprintf(nm, sizeof(nm), "conv_bf16_kernel<%d, %d>", MT, NW);
-    snprintf(tag, sizeof(tag), "C=%d N=%d T=%d K=%d ld=%d B=%d nck=%d grid=%lld", a.C0 + a.C1, a.N, a.Tout, a.KW, a.loader, a.B,
-             NCK, grid);
+    snprintf(nm, sizeof(nm), "conv_bf16_kernel<%d, %d%s>", MT, NW, tpw > 1 ? ", ws" : "");
+    snprintf(tag, sizeof(tag), "C=%d N=%d T=%d K=%d ld=%d B=%d nck=%d tpw=%d grid=%lld", a.C0 + a.C1, a.N, a.Tout, a.KW, a.loader,
+             a.B, NCK, tpw, grid);
     prof_scope_begin(nm, conv_flops(a), s, tag);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a, nTT, nNT, NCK, ROWS);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a, nTT, nNT, NCK, ROWS, tpw);
     prof_scope_end(s);
     return hipGetLastError();
 }
@@ -369,6 +462,7 @@ hipError_t launch_conv_bf16(const ConvArgs& a_in, hipStream_t s) {
     if (a.msk1 != nullptr) vec = vec && al16(a.msk1);
     if (a.dec != nullptr) vec = vec && (a.decpitch & 1) == 0 && (a.decbs & 1) == 0;
     if (vec) a.flags |= F_VEC4;
+    if (const char* e = getenv("WUN_BF_ABL")) a.flags |= atoi(e) << 16;      // diagnostic: skip phases of the kernel
     // tile: fewest padded columns among 64/48/32; rows by how many tiles the launch has
     int bestnw = 4, bestpad = 1 << 30;
     const int cands[3] = {4, 3, 2};
@@ -381,6 +475,16 @@ hipError_t launch_conv_bf16(const ConvArgs& a_in, hipStream_t s) {
     int mt = 4;
     while (mt > 1 && ((long long)((a.Tout + 64 * mt - 1) / (64 * mt)) * cols * a.B < 512 || a.Tout <= 32 * mt ||
                       bf16_lds(a, 64 * mt, bestnw * 16, 1) > 160 * 1024)) mt >>= 1;
+    // A workgroup runs its phases (fetch, MFMA, store) back to back, so the CU needs a second resident workgroup to
+    // overlap them: take the tallest tile whose LDS footprint still lets two workgroups share a CU
+    static const int lds_cap = getenv("WUN_BF16_LDS_CAP") ? atoi(getenv("WUN_BF16_LDS_CAP")) : 80;
+    {
+        int m2 = mt;
+        while (m2 > 1 && bf16_lds(a, 64 * m2, bestnw * 16, bf16_pick_nck(a, 64 * m2, bestnw * 16, m2 == 4 ? 9 : (m2 == 2 ? 7 : 4))) >
+                             (size_t)lds_cap * 1024) m2 >>= 1;
+        if (bf16_lds(a, 64 * m2, bestnw * 16, bf16_pick_nck(a, 64 * m2, bestnw * 16, m2 == 4 ? 9 : (m2 == 2 ? 7 : 4))) <= (size_t)lds_cap * 1024)
+            mt = m2;
+    }
 #define WUN_BF(M, N) if (mt == M && bestnw == N) return conv_bf16_launch_t<M, N>(a, s);
     WUN_BF(4, 4) WUN_BF(4, 3) WUN_BF(4, 2)
     WUN_BF(2, 4) WUN_BF(2, 3) WUN_BF(2, 2)

@@ -143,7 +143,7 @@ struct wun_plan {
     // workspace, keyed by where the fp32 weights of a launch live (params arena / transposed copy in ws)
     struct BfImg { long long off; int c8p, npad; };
     bool bf16 = false;
-    long long bf16_min_rows = 16384;                         // smaller launches stay on the exact-fp32 kernels
+    long long bf16_min_rows = 0;                             // launches with fewer output rows stay on the exact-fp32 kernels (WUN_BF16_MIN_ROWS)
     std::map<std::pair<int, long long>, BfImg> bf_img;       // (1 = in workspace, float offset) -> image
     std::vector<PackDesc> pack;                              // forward images first, then the dgrad images
     int npack_fwd = 0;
