@@ -192,6 +192,14 @@ hipError_t launch_narrow_wgrad_reduce(const NarrowWgradArgs& a, const float* par
                                       const long long* woff, const long long* boff, hipStream_t s);
 
 // ---- bf16-MFMA speed mode (wun_bf16.hip) ----
+// 8-channel groups of a packed bf16 weight image for C input channels: the conv kernel reads whole stages of
+// 4, 8 or 12 groups (1..3 chunks of 32 channels), so the image is zero-padded to the next multiple of each
+static inline int bf16_image_groups(int C) {
+    const int g = (C + 7) / 8;
+    int best = 0;
+    for (int m = 4; m <= 12; m += 4) { const int r = (g + m - 1) / m * m; best = r > best ? r : best; }
+    return best;
+}
 bool conv_bf16_supported(const ConvArgs& a);
 bool conv_bf16_preferred(const ConvArgs& a, long long min_rows);
 hipError_t launch_conv_bf16(const ConvArgs& a, hipStream_t s);

@@ -153,6 +153,17 @@ __device__ __forceinline__ int xcd_contiguous_block(int bid, int grid) {
 
 #define WUN_JMAX 15
 
+// floor(n / d) for 0 <= n < 2^22, d >= 1 with inv = 1.0f / d: one multiply + a +/-1 fix-up instead of the ~35
+// instruction integer division (the batch-folded tiles of the deep, launch-latency-bound levels do a dozen of
+// these per thread before their first load)
+__device__ __forceinline__ int fast_div(int n, int d, float inv) {
+    int q = (int)(((float)n + 0.5f) * inv);
+    const int r = n - q * d;
+    q += (r >= d) ? 1 : 0;
+    q -= (r < 0) ? 1 : 0;
+    return q;
+}
+
 //
 // FOLD variants (deep levels, few output positions per excerpt): the GEMM M axis is the flattened
 // (excerpt, position) index, so one workgroup tile spans several excerpts and every weight slab
@@ -190,14 +201,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
     int bid = xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x);
     const int nt = bid % nNT; bid /= nNT;
     const int tt = bid % nTT; bid /= nTT;
-    const int b = FOLD ? (tt * TT) / a.Tout : bid % a.B;      // FOLD: first excerpt of the tile
+    const float inv_tout = 1.0f / (float)a.Tout;
+    const int b = FOLD ? fast_div(tt * TT, a.Tout, inv_tout) : bid % a.B;      // FOLD: first excerpt of the tile
     const int ksp = FOLD ? bid : bid / a.B;
     const int q0 = tt * TT, n0 = nt * NT;                     // FOLD: q0 = first flattened row
     // FOLD: excerpts touched by this tile and the per-excerpt segment length in the LDS row
     int fold_nb = 1;
     const int fold_seg = a.Tout + J - 1;
     if constexpr (FOLD) {
-        int last = (q0 + TT - 1) / a.Tout;
+        int last = fast_div(q0 + TT - 1, a.Tout, inv_tout);
         if (last > a.B - 1) last = a.B - 1;
         fold_nb = last - b + 1;
     }
@@ -239,11 +251,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
         const int lim = deint ? 2 * UW : UW;
         const int tbase = (deint ? 2 * q0 : q0) - a.shift;
         const int seglen = deint ? 2 * fold_seg : fold_seg;
+        const float inv_seglen = 1.0f / (float)seglen;
 #pragma unroll
         for (int i = 0; i < XIT; ++i) {
             const int u = lr + i * stride_i;
             int t = tbase + u, bl = 0;
-            if constexpr (FOLD) { bl = u / seglen; t = u - bl * seglen - a.shift; }
+            if constexpr (FOLD) { bl = fast_div(u, seglen, inv_seglen); t = u - bl * seglen - a.shift; }
             const bool ok = u < lim && t >= 0 && t < a.Tin;
             int tc = t < 0 ? 0 : t;
             if (tc > a.Tin - 1) tc = a.Tin - 1;
@@ -373,7 +386,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
         arow[m] = 0;
         if constexpr (FOLD) {
             const int row = q0 + wt0 + m * 16 + li;
-            int g = row / a.Tout;
+            int g = fast_div(row, a.Tout, inv_tout);
             const int q = row - g * a.Tout;
             g -= b;
             arow[m] = g < fold_nb ? g * fold_seg + q : 0;      // rows past the last excerpt: results discarded
@@ -496,7 +509,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
             for (int m = 0; m < MT; ++m) {
                 const int q = q0 + wt0 + m * 16 + lg * 4;
                 if constexpr (FOLD) {
-                    int g = q / a.Tout, qq = q - g * a.Tout;
+                    int g = fast_div(q, a.Tout, inv_tout), qq = q - g * a.Tout;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         if (g < a.B) a.part[(((long long)ksp * a.B + g) * a.N + ncol) * TP + qq] = acc[m][n][r];
@@ -590,7 +603,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
         for (int m = 0; m < MT; ++m) {
             const int q = q0 + wt0 + m * 16 + lg * 4;
             if constexpr (FOLD) {
-                int g = q / a.Tout, qq = q - g * a.Tout;
+                int g = fast_div(q, a.Tout, inv_tout), qq = q - g * a.Tout;
                 const bool first = ncol < a.N0;
                 const long long colbase = first ? (long long)ncol * a.opitch0 + a.ooff0
                                                 : (long long)(ncol - a.N0) * a.opitch1 + a.ooff1;

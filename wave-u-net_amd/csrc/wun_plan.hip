@@ -139,6 +139,7 @@ struct wun_plan {
     // forward pass (training mode) so that the backward pass does not start with a 50 us transpose
     mutable hipEvent_t wt_ev = nullptr;
     mutable bool wt_ready = false;
+    mutable std::vector<hipEvent_t> skip_ev;             // forward: skip window i is complete (deferred window convs)
     // bf16-MFMA speed mode (cfg.compute_dtype == 1): packed bf16 images of the conv weights in the
     // workspace, keyed by where the fp32 weights of a launch live (params arena / transposed copy in ws)
     struct BfImg { long long off; int c8p, npad; };
@@ -346,7 +347,7 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
             if (Cc < 8 || K < 1) return;
             PackDesc d;
             d.src_off = src_off; d.src_in_ws = in_ws; d.KW = K; d.C = Cc; d.N = Nn;
-            d.C8p = (Cc + 31) / 32 * 4; d.Npad = (Nn + 63) / 64 * 64;
+            d.C8p = bf16_image_groups(Cc); d.Npad = (Nn + 63) / 64 * 64;
             const long long items = (long long)K * d.C8p * d.Npad;
             d.dst_off = bump(w, items * 4);                     // 8 bf16 = 4 floats per item
             p->pack.push_back(d);
@@ -436,6 +437,7 @@ extern "C" void wun_plan_destroy(wun_plan* p) {
     for (auto e : p->events) (void)hipEventDestroy(e);
     if (p->tev0) { (void)hipEventDestroy(p->tev0); (void)hipEventDestroy(p->tev1); }
     if (p->wt_ev) (void)hipEventDestroy(p->wt_ev);
+    for (auto e : p->skip_ev) (void)hipEventDestroy(e);
     if (p->side) (void)hipStreamDestroy(p->side);
     if (p->side2) (void)hipStreamDestroy(p->side2);
     delete p;
@@ -562,9 +564,11 @@ static float time_launch(const wun_plan* p, hipStream_t s, const std::function<h
     return best;
 }
 
-static hipError_t conv_dispatch(const wun_plan* p, ConvArgs a, float* part, long long cap, hipStream_t s) {
+// at < 0: the launch takes the next position of the step's launch order; at >= 0: a position reserved earlier
+// (deferred launches keep the position they have in the canonical order, so tuned tables stay aligned)
+static hipError_t conv_dispatch(const wun_plan* p, ConvArgs a, float* part, long long cap, hipStream_t s, long long at = -1) {
     std::vector<ConvChoice>& vec = p->in_bwd ? p->conv_bwd : p->conv_fwd;
-    const size_t idx = p->ci++;
+    const size_t idx = at >= 0 ? (size_t)at : p->ci++;
     if (p->bf16 && conv_bf16_preferred(a, p->bf16_min_rows)) {
         // bf16-MFMA speed mode: same launch, operands rounded to bf16, weights from the packed image
         const bool in_ws = a.W >= p->cur_ws && a.W < p->cur_ws + p->ws;
@@ -639,6 +643,26 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
     }
     HIP_TRY(launch_btc_to_ncw(mix_btc, ws + p->mix_ncw.off, p->B, p->Tin, p->C, p->mix_ncw.pitch, s));
 
+    // Context mode: the skip-window conv of level i is only consumed by up level L-1-i, i.e. the windows of the
+    // shallow, FLOP-heavy levels are needed LAST.  The deep levels (few positions per excerpt) form a dependent
+    // chain of launch-latency-bound kernels that leaves most CUs idle, so the shallow levels' window convs are
+    // deferred: queued on a third stream once the deep chain starts (deepest-needed first) and awaited per level
+    // by the up path.  They fill the idle CUs instead of competing with their own level's decimating conv.
+    int defer_below = 0;                                            // levels [0, defer_below) are deferred
+    hipStream_t s3 = (p->side2 && s2 != s) ? p->side2 : s2;
+    if (!same && s3 != s2 && getenv("WUN_NO_DEFER") == nullptr) {
+        while (defer_below < L && (long long)p->B * p->dsh[defer_below].t_dec >= 16384) ++defer_below;
+        if (L - defer_below < 3) defer_below = 0;                   // no deep chain to hide them under
+        if (defer_below > 0 && p->skip_ev.size() < (size_t)L) {
+            p->skip_ev.resize(L, nullptr);
+            for (auto& e : p->skip_ev)
+                if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+    }
+    std::vector<ConvArgs> deferred((size_t)defer_below);
+    std::vector<long long> deferred_pos((size_t)defer_below, -1);
+    const long long part_half = p->conv_part_floats / 2, part_q = p->conv_part_floats / 4;
+
     const Buf* x = &p->mix_ncw;
     for (int i = 0; i < L; ++i) {                                   // :97-100
         const DownShape& d = p->dsh[i];
@@ -669,8 +693,22 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
             b.Tin = d.tc + Kd - 1; b.shift = 0; b.W = params + cl.woff; b.bias = params + cl.boff;
             b.KW = Kd; b.N = b.N0 = d.cout; b.Tout = d.tc; b.flags = F_LRELU;
             set_dst0(b, ws, p->skip[i], 0, nullptr);
-            HIP_TRY(conv_dispatch(p, b, ws + p->conv_part_off + p->conv_part_floats / 2, p->conv_part_floats / 2, s2));
-            side_used = side_used || (s2 != s);
+            if (i < defer_below) {
+                deferred[(size_t)i] = b;
+                deferred_pos[(size_t)i] = (long long)p->ci++;       // its position in the canonical launch order
+            } else {
+                HIP_TRY(conv_dispatch(p, b, ws + p->conv_part_off + part_half, part_q, s2));
+                side_used = side_used || (s2 != s);
+            }
+            if (defer_below > 0 && i == defer_below - 1) {
+                // every input the deferred windows read has been issued on `s`: start them on the third stream
+                if ((rc0 = stream_dep(p, s, s3))) return rc0;
+                for (int k = defer_below - 1; k >= 0; --k) {
+                    HIP_TRY(conv_dispatch(p, deferred[(size_t)k], ws + p->conv_part_off + part_half + part_q, part_q, s3,
+                                          deferred_pos[(size_t)k]));
+                    HIP_TRY(hipEventRecord(p->skip_ev[(size_t)k], s3));
+                }
+            }
         }
         x = &p->dec[i];
     }
@@ -693,6 +731,7 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
         ua.w = p->interp[j] >= 0 ? params + p->interp[j] : nullptr;
         ua.C = u.c_cur; ua.B = p->B; ua.context = p->cfg.context;
         HIP_TRY(launch_upsample(ua, s));
+        if (L - 1 - j < defer_below) HIP_TRY(hipStreamWaitEvent(s, p->skip_ev[(size_t)(L - 1 - j)], 0));
         ConvArgs a = conv_base(p);
         set_src0(a, ws, p->skip[L - 1 - j], 0, u.c_skip);          // crop already applied when it was written
         set_src1(a, ws, p->ups[j], 0, u.c_cur);
@@ -1134,7 +1173,7 @@ extern "C" int wun_plan_tune(const wun_plan* p, const float* params, const float
 // Tuning-table header: identifies the plan (every config key that changes a launch), the launch
 // order of this library build and the number of entries per section, so a table written for
 // another plan, another library build or truncated on disk is rejected at import.
-#define WUN_TUNE_ORDER "r2b"      /* bump whenever the order / number of conv or wgrad launches changes */
+#define WUN_TUNE_ORDER "r2c"      /* bump whenever the order / number of conv or wgrad launches changes */
 static std::string tune_header(const wun_plan* p, size_t ncf, size_t ncb, size_t nwg) {
     char line[320];
     const wun_config& c = p->cfg;
@@ -1424,7 +1463,7 @@ extern "C" int wun_op_conv1d_ex(const float* x0, int c0, const float* x1, int c1
 // bf16-MFMA conv as a single operator: packs w (fp32 [K][Cin][Cout]) into the bf16 image in `scratch`
 // (>= wun_op_conv1d_bf16_scratch floats), then runs the bf16 kernel.  Same semantics as wun_op_conv1d.
 extern "C" int64_t wun_op_conv1d_bf16_scratch(int cin, int cout, int k) {
-    return (int64_t)k * ((cin + 31) / 32 * 4) * ((cout + 63) / 64 * 64) * 4 + 64;
+    return (int64_t)k * bf16_image_groups(cin) * ((cout + 63) / 64 * 64) * 4 + 64;
 }
 
 extern "C" int wun_op_conv1d_bf16(const float* x, const float* w, const float* bias, float* y, float* scratch,
@@ -1445,7 +1484,7 @@ extern "C" int wun_op_conv1d_bf16(const float* x, const float* w, const float* b
     float* img = (float*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
     PackDesc d;
     d.src_off = 0; d.src_in_ws = 0; d.dst_off = 0; d.KW = k; d.C = cin; d.N = cout;
-    d.C8p = (cin + 31) / 32 * 4; d.Npad = (cout + 63) / 64 * 64;
+    d.C8p = bf16_image_groups(cin); d.Npad = (cout + 63) / 64 * 64;
     PackDesc* dd = nullptr;
     HIP_TRY(hipMalloc((void**)&dd, sizeof(PackDesc)));
     hipError_t e = hipMemcpyAsync(dd, &d, sizeof(d), hipMemcpyHostToDevice, s);
