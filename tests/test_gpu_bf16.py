@@ -80,6 +80,8 @@ BF16_CONV_CASES = [
     (2, 600, 288, 5, 17, 1, 0, False),
     (2, 13, 12, 4, 90, 1, 1, True),
     (2, 9, 8, 7, 91, 2, 0, False),
+    (3, 72, 24, 5, 1500, 1, 0, False),      # two 64-channel stages over 72 channels: the second stage is mostly padding
+    (2, 136, 40, 5, 900, 1, 0, False),
     (16, 120, 144, 15, 2305, 2, 0, False),
     (16, 168, 72, 5, 4105, 1, 0, False),
     (1, 96, 120, 15, 260, 2, 0, False),
@@ -100,7 +102,8 @@ def test_op_conv1d_bf16_is_exact_up_to_operand_rounding(lib, case):
     ref = torch.maximum(0.2 * ref, ref).numpy()
     y = torch.full((B, Cout, t_out), float("nan"), device="cuda")
     dx, dw, db_ = _cuda(x), _cuda(w), _cuda(b)
-    scr = torch.empty(int(lib.wun_op_conv1d_bf16_scratch(Cin, Cout, K)), device="cuda")
+    # NaN-poisoned scratch: a read outside the packed weight image would surface as NaN in the output
+    scr = torch.full((int(lib.wun_op_conv1d_bf16_scratch(Cin, Cout, K)) + 4096,), float("nan"), device="cuda")
     _lib.check(lib.wun_op_conv1d_bf16(dx.data_ptr(), dw.data_ptr(), db_.data_ptr(), y.data_ptr(), scr.data_ptr(), B, Cin,
                                       Cout, K, T, t_out, stride, pad, 1, _stream()))
     torch.cuda.synchronize()

@@ -38,3 +38,15 @@ cd $R
 python tools/pmc_report.py gpurun_out/${tag}_pmc_FETCH_SIZE.json gpurun_out/${tag}_pmc_WRITE_SIZE.json gpurun_out/${tag}_pmc_mfma.json \
     gpurun_out/${tag}_pmc_traffic.json gpurun_out/${tag}_pmc_mfma_util.txt "$tag" $WUN_TUNE_CACHE
 tail -1 gpurun_out/${tag}_bench.json | cut -c1-400
+# the other BASELINE.json configs, fp32 and the bf16 speed mode (named-config benches; no CPU baseline)
+if [ "${CFGS:-1}" = 1 ]; then
+    unset WUN_TUNE_CACHE
+    for c in baseline baseline_stereo full full_multi_instrument; do
+        python bench.py --config $c --no-cpu-baseline > gpurun_out/${tag}_cfg_${c}_f32.json 2> gpurun_out/${tag}_cfg_${c}_f32.err
+        python bench.py --config $c --dtype bf16 --no-cpu-baseline > gpurun_out/${tag}_cfg_${c}_bf16.json 2> gpurun_out/${tag}_cfg_${c}_bf16.err
+    done
+    python bench.py --dtype bf16 --no-cpu-baseline > gpurun_out/${tag}_cfg_m1_context_bf16.json 2> gpurun_out/${tag}_cfg_m1_context_bf16.err
+    WUN_NO_TUNE=1 python bench.py --config deep_l16_f48 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_cfg_deep_f32.json 2> gpurun_out/${tag}_cfg_deep_f32.err
+    WUN_NO_TUNE=1 python bench.py --config deep_l16_f48 --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_cfg_deep_bf16.json 2> gpurun_out/${tag}_cfg_deep_bf16.err
+    for f in gpurun_out/${tag}_cfg_*.json; do echo "$f: $(cut -c1-200 $f)"; done
+fi
