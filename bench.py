@@ -38,7 +38,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide: dense bf16 MFMA (the 5 PF headli
 
 
 def family_peak(family):
-    return PEAK_BF16_MFMA_TFLOPS if family.startswith("conv_bf16") else PEAK_FP32_MFMA_TFLOPS
+    return PEAK_BF16_MFMA_TFLOPS if "_bf16_" in family else PEAK_FP32_MFMA_TFLOPS
 _T0 = time.time()
 
 

@@ -145,21 +145,30 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(NarrowWgradArgs a) {
     }
 }
 
-// out element (k, ci, n = s*Nper + c) -> source s: weights [K][Ctot][Nper] at woff[s], bias at boff[s]
+// out element (k, ci, n = s*Nper + c) -> source s: weights [K][Ctot][Nper] at woff[s], bias at boff[s].
+// One workgroup per output element: 256 threads sum the splits (thread t takes splits t, t+256, ...), then a
+// fixed-order tree through LDS -- deterministic, and ~nsplit/256 dependent loads per thread instead of nsplit.
 __global__ __launch_bounds__(256) void narrow_wgrad_reduce_kernel(const float* partial, int nsplit, int KW, int Ctot, int N,
                                                                   int Nper, float* grads, long long w0, long long w1,
                                                                   long long w2, long long w3, long long b0, long long b1,
                                                                   long long b2, long long b3) {
+    __shared__ float red[256];
     const long long woff[4] = {w0, w1, w2, w3}, boff[4] = {b0, b1, b2, b3};
     const int P = (KW * Ctot + 1) * N;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P) return;
+    const int i = blockIdx.x;
     float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += partial[(long long)k * P + i];
+    for (int k = threadIdx.x; k < nsplit; k += 256) s += partial[(long long)k * P + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
     const int n = i % N, r = i / N;
     const int src = n / Nper, c = n - src * Nper;
-    if (r < KW * Ctot) grads[woff[src] + (long long)r * Nper + c] = s;
-    else grads[boff[src] + c] = s;
+    if (r < KW * Ctot) grads[woff[src] + (long long)r * Nper + c] = red[0];
+    else grads[boff[src] + c] = red[0];
 }
 
 bool narrow_wgrad_supported(const NarrowWgradArgs& a) {
@@ -228,7 +237,7 @@ hipError_t launch_narrow_wgrad(NarrowWgradArgs a, hipStream_t s) {
 hipError_t launch_narrow_wgrad_reduce(const NarrowWgradArgs& a, const float* partial, int nsplit, float* grads,
                                       const long long* woff, const long long* boff, hipStream_t s) {
     const int P = (int)narrow_wgrad_partial_floats(a);
-    hipLaunchKernelGGL(narrow_wgrad_reduce_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, partial, nsplit, a.KW,
+    hipLaunchKernelGGL(narrow_wgrad_reduce_kernel, dim3((unsigned)P), dim3(256), 0, s, partial, nsplit, a.KW,
                        a.C0 + a.C1, a.N, a.Nper, grads, woff[0], woff[1], woff[2], woff[3], boff[0], boff[1], boff[2], boff[3]);
     return hipGetLastError();
 }

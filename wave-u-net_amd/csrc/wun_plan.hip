@@ -1059,10 +1059,8 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
         const DownShape& d = p->dsh[i];
         const ConvLayer& cl = p->down[i];
         const Buf& x = (i == 0) ? p->mix_ncw : p->dec[i - 1];
-        // the audio-input conv (1 or 2 input channels) can use the direct-reduction kernel too (WUN_NARROW_DOWN0=1).
-        // Off by default: it is the LAST launch of the backward pass, and although the kernel alone is faster than
-        // the MFMA tiles (65 vs 72 us for the decimated part), its many LDS-heavy workgroups compete with the
-        // final input-gradient convs for CUs -- measured +0.13..0.4 ms per step
+        // the audio-input conv (1 or 2 input channels): direct reduction instead of MFMA tiles (10 TFLOP/s of mostly
+        // padding); WUN_NO_NARROW_DOWN0=1 keeps the MFMA kernel (A/B: 9.36 -> 9.32 ms per step with the narrow kernel)
         NarrowWgradArgs nw[2];
         bool narrow = false;
         if (i == 0) {
@@ -1080,7 +1078,7 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
                 nw[1].Tin = d.tc + Kd - 1; nw[1].shift = 0; nw[1].stride = 1; nw[1].off0 = d.cs;
                 nw[1].dz = ws + p->dz_skip[0].off; nw[1].dzbs = p->dz_skip[0].bs; nw[1].dzpitch = p->dz_skip[0].pitch; nw[1].Tq = d.tc;
             }
-            narrow = narrow_wgrad_supported(nw[0]) && (same || narrow_wgrad_supported(nw[1])) && getenv("WUN_NARROW_DOWN0") != nullptr;
+            narrow = narrow_wgrad_supported(nw[0]) && (same || narrow_wgrad_supported(nw[1])) && getenv("WUN_NO_NARROW") == nullptr && getenv("WUN_NO_NARROW_DOWN0") == nullptr;
         }
         if (narrow) {
             const long long woff[4] = {cl.woff, 0, 0, 0}, boff[4] = {cl.boff, 0, 0, 0};
@@ -1173,7 +1171,7 @@ extern "C" int wun_plan_tune(const wun_plan* p, const float* params, const float
 // Tuning-table header: identifies the plan (every config key that changes a launch), the launch
 // order of this library build and the number of entries per section, so a table written for
 // another plan, another library build or truncated on disk is rejected at import.
-#define WUN_TUNE_ORDER "r2c"      /* bump whenever the order / number of conv or wgrad launches changes */
+#define WUN_TUNE_ORDER "r2d"      /* bump whenever the order / number of conv or wgrad launches changes */
 static std::string tune_header(const wun_plan* p, size_t ncf, size_t ncb, size_t nwg) {
     char line[320];
     const wun_config& c = p->cfg;
