@@ -216,6 +216,13 @@ int wun_op_conv1d_bf16(const float* x, const float* w, const float* bias, float*
                        int batch, int cin, int cout, int k, int t_in, int t_out, int stride, int pad_left,
                        int lrelu, void* stream);
 
+/* Input gradient in the bf16 speed mode (wun_op_conv1d_dgrad semantics; stride 2 = the fused two-phase transposed
+ * conv, pad_left 0 and cin % 4 == 0).  scratch: device floats, >= wun_op_conv1d_dgrad_bf16_scratch(cin, cout, k).
+ * Synchronises the stream. */
+int64_t wun_op_conv1d_dgrad_bf16_scratch(int cin, int cout, int k);
+int wun_op_conv1d_dgrad_bf16(const float* dz, const float* w, float* dx, float* scratch, int batch, int cin,
+                             int cout, int k, int t_in, int t_out, int stride, int pad_left, void* stream);
+
 /* Lane layout probe of v_mfma_f32_16x16x32_bf16: d[16][16] = bf16(a[16][32]) * bf16(b[32][16]) (row-major). */
 int wun_op_mfma_bf16_probe(const float* a, const float* b, float* d, void* stream);
 

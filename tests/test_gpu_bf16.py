@@ -114,6 +114,44 @@ def test_op_conv1d_bf16_is_exact_up_to_operand_rounding(lib, case):
     assert err <= OP_TOL
 
 
+BF16_DGRAD_CASES = [
+    # (B, Cin, Cout, K, T_in, stride)
+    (2, 24, 48, 15, 1400, 2),
+    (2, 48, 72, 15, 1201, 2),
+    (16, 72, 96, 15, 2057, 2),
+    (2, 96, 24, 7, 1000, 2),
+    (3, 264, 288, 15, 59, 2),
+    (2, 24, 48, 15, 700, 1),
+    (2, 72, 24, 5, 900, 1),
+]
+
+
+@pytest.mark.parametrize("case", BF16_DGRAD_CASES, ids=[str(c) for c in BF16_DGRAD_CASES])
+def test_op_dgrad_bf16_is_exact_up_to_operand_rounding(lib, case):
+    """Input gradient in the speed mode -- stride 2 = the fused two-phase transposed conv -- against the float64
+    gradient computed from the bf16-rounded dz and weights."""
+    B, Cin, Cout, K, T, stride = case
+    t_out = (T - K) // stride + 1
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31) + 23)
+    w = (rng.uniform(-1, 1, (K, Cin, Cout)) / np.sqrt(K * Cin)).astype(np.float32)
+    dz = rng.uniform(-1, 1, (B, Cout, t_out)).astype(np.float32)
+    xt = torch.zeros((B, Cin, T), dtype=torch.float64, requires_grad=True)
+    yy = F.conv1d(xt, torch.tensor(_bf16_round(w)).permute(2, 1, 0), None, stride=stride)
+    (yy * torch.tensor(_bf16_round(dz))).sum().backward()
+    ref = xt.grad.numpy()
+    dw, dzg = _cuda(w), _cuda(dz)
+    scr = torch.full((int(lib.wun_op_conv1d_dgrad_bf16_scratch(Cin, Cout, K)) + 4096,), float("nan"), device="cuda")
+    gdx = torch.full((B, Cin, T), float("nan"), device="cuda")
+    _lib.check(lib.wun_op_conv1d_dgrad_bf16(dzg.data_ptr(), dw.data_ptr(), gdx.data_ptr(), scr.data_ptr(), B, Cin, Cout, K, T,
+                                            t_out, stride, 0, _stream()))
+    torch.cuda.synchronize()
+    got = gdx.cpu().numpy()
+    assert np.isfinite(got).all()
+    err = np.abs(got - ref).max() / max(1.0, np.abs(ref).max())
+    record("op_dgrad_bf16_vs_rounded_operands", str(case), err, OP_TOL)
+    assert err <= OP_TOL
+
+
 BF16_WGRAD_CASES = [
     # (B, Cin, Cout, K, T, stride, pad_left, same)
     (2, 24, 48, 15, 700, 1, 0, False),

@@ -51,6 +51,8 @@ _SIGS = {
     "wun_op_mfma_bf16_probe": (C.c_int, [_P, _P, _P, _P]),
     "wun_op_conv1d_bf16_scratch": (C.c_int64, [C.c_int] * 3),
     "wun_op_conv1d_bf16": (C.c_int, [_P, _P, _P, _P, _P] + [C.c_int] * 9 + [_P]),
+    "wun_op_conv1d_dgrad_bf16_scratch": (C.c_int64, [C.c_int] * 3),
+    "wun_op_conv1d_dgrad_bf16": (C.c_int, [_P, _P, _P, _P] + [C.c_int] * 8 + [_P]),
     "wun_op_force_conv_variant": (C.c_int, [C.c_int, C.c_int]),
     "wun_op_num_conv_variants": (C.c_int, []),
     "wun_op_force_wgrad_variant": (C.c_int, [C.c_int, C.c_int, C.c_int]),

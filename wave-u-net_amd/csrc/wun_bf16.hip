@@ -95,7 +95,11 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
     int bid = xcd_block((int)blockIdx.x, (int)gridDim.x);
     const int nt = bid % nNT;
     const int seg = bid / nNT;
-    const int n0 = nt * NT;
+    // fused two-phase transposed stride-2 conv (F_PHASE2): the weight matrix has 2*N columns (phase 0 | phase 1 of the N
+    // output channels); a workgroup takes NT/2 channels x both phases -- column tiles [0, NW/2) are phase 0 (outputs
+    // t = 2q), tiles [NW/2, NW) phase 1 (t = 2q + 1) of the SAME channels, so a lane owns 8 consecutive output samples
+    const bool phase2 = (a.flags & F_PHASE2) != 0;
+    const int n0 = phase2 ? nt * (NT / 2) : nt * NT;
     const int wt0 = wave * MT * 16;
     const int tix0 = seg * tpw;
     int tix1 = tix0 + tpw;
@@ -127,18 +131,24 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
         xfl[i] = tr | (c8l << 24) | ((live ? 1 : 0) << 29);
         xlo[i] = (pl * ROWS + row) * XPB + c8l * 16;
     }
-    const float* src0b = a.src0;
-    const float* src1b = a.src0;
+    // Input rows are fetched with raw buffer loads: resource = this excerpt's tensor, SGPR offset = channel row
+    // (one s_mul per load), VGPR offset = the lane's time index.  A flat load needs ~8 scalar instructions of 64-bit
+    // address arithmetic per row pointer; at bf16 MFMA rates that arithmetic, not the matrix pipe, set the stage time.
+    __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, 0x7FFFFFFE, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs1 = rs0;
+    const int pb0 = a.pitch0 * 4, pb1 = a.pitch1 * 4;      // row pitches in bytes
     auto set_tile = [&](int tix, int& b, int& q0) {
         b = tix / nTT;
         q0 = (tix - b * nTT) * TT;
-        src0b = a.src0 + (long long)b * a.bs0 + a.off0;
-        src1b = (a.src1 != nullptr) ? a.src1 + (long long)b * a.bs1 + a.off1 : src0b;
+        rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src0 + (long long)b * a.bs0 + a.off0), 0, 0x7FFFFFFE, 0x00020000);
+        rs1 = (a.src1 != nullptr)
+                  ? __builtin_amdgcn_make_buffer_rsrc((void*)(a.src1 + (long long)b * a.bs1 + a.off1), 0, 0x7FFFFFFE, 0x00020000)
+                  : rs0;
         const int tq = (deint ? 2 * q0 : q0) - 64;
 #pragma unroll
         for (int i = 0; i < XIT; ++i) {
             const int t = (xfl[i] & 0xFFFFFF) + tq;
-            const int tc = t < 0 ? 0 : (t > a.Tin - 1 ? a.Tin - 1 : t);      // Tin < 2^24 (checked by the launcher)
+            const int tc = t < 0 ? 0 : (t > a.Tin - 1 ? a.Tin - 1 : t);      // Tin < 2^23 (checked by the launcher)
             xti[i] = tc | ((t >= 0 && t < a.Tin ? 1 : 0) << 28);
         }
     };
@@ -148,14 +158,17 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
 #pragma unroll
         for (int i = 0; i < XIT; ++i) {
             if (i * 256 < nxitems) {                         // uniform
-                const unsigned t = (unsigned)(xti[i] & 0xFFFFFF);
+                const int tb = (xti[i] & 0xFFFFFF) * 4;      // byte offset of the lane's time index
                 const int cbase = st * CKW + __builtin_amdgcn_readfirstlane((xfl[i] >> 24) & 15) * 8;     // wave-uniform
+                // a group of 8 channels lies in ONE source (C0 % 8 == 0, checked by the launcher)
+                const bool s1 = cbase >= a.C0;
+                const __amdgpu_buffer_rsrc_t rs = s1 ? rs1 : rs0;
+                const int c0 = s1 ? cbase - a.C0 : cbase, cmax = (s1 ? a.C1 : a.C0) - 1, pb = s1 ? pb1 : pb0;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    int c = cbase + e;
-                    c = c < Ctot ? c : Ctot - 1;
-                    const float* p = c < a.C0 ? src0b + (long long)c * a.pitch0 : src1b + (long long)(c - a.C0) * a.pitch1;
-                    xreg[i][e] = p[t];
+                    int c = c0 + e;
+                    c = c < cmax ? c : cmax;                 // channels past the tensor: any valid row (zero-filled at the store)
+                    xreg[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, tb, c * pb, 0));
                 }
             }
         }
@@ -183,12 +196,13 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
     for (int k = 0; k < 3; ++k) {
         const int r = k * 256 + tid;
         const int c8l = r / NT, n = r - c8l * NT;           // NT is a compile-time constant: no integer division
-        wofs[k] = r < per_tap ? (c8l * a.wb_npad + n) * 8 : -1;
+        const int gcol = !phase2 ? n0 + n : (n < NT / 2 ? n0 + n : a.N + n0 + (n - NT / 2));   // column in the image
+        wofs[k] = r < per_tap ? (c8l * a.wb_npad + gcol) * 8 : -1;
     }
     auto dma_w = [&](int st, int buf) {
         unsigned char* wbuf = Ws + buf * wbytes;
         for (int j = 0; j < KW; ++j) {
-            const unsigned short* wj = Wb + (((long long)j * a.wb_c8p + st * C8S) * a.wb_npad + n0) * 8;
+            const unsigned short* wj = Wb + (((long long)j * a.wb_c8p + st * C8S) * a.wb_npad) * 8;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 if (k * 256 < per_tap && wofs[k] >= 0)
@@ -255,7 +269,58 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
         const int ncol = n0 + n * 16 + li;
         e_bv[n] = (e_bias != nullptr && ncol < e_N) ? e_bias[ncol] : 0.f;
     }
+    const int e_Tlim = a.Tlim;
     auto epilogue = [&](int b, int q0) {
+        if (phase2) {
+            if constexpr ((NW % 2) == 0) {
+#pragma unroll
+                for (int n = 0; n < NW / 2; ++n) {
+                    const int ncol = n0 + n * 16 + li;
+                    if (ncol >= e_N) continue;
+                    const long long rowbase = (long long)b * e_obs0 + (long long)ncol * e_op0 + e_oo0;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const int q = q0 + wt0 + m * 16 + lg * 4;
+                        const int t0 = 2 * q;
+                        float v[8];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { v[2 * r] = acc[m][n][r]; v[2 * r + 1] = acc[m][NW / 2 + n][r]; }
+                        if (vec && t0 + 7 < e_Tlim) {
+                            const long long idx = rowbase + t0;
+                            if (e_msk0 != nullptr) {
+                                const f32x4 m0 = *reinterpret_cast<const f32x4*>(&e_msk0[idx]);
+                                const f32x4 m1 = *reinterpret_cast<const f32x4*>(&e_msk0[idx + 4]);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    v[r] *= (m0[r] > 0.f) ? 1.f : 0.2f;
+                                    v[4 + r] *= (m1[r] > 0.f) ? 1.f : 0.2f;
+                                }
+                            }
+                            if (accum) {
+                                const f32x4 o0 = *reinterpret_cast<const f32x4*>(&e_dst0[idx]);
+                                const f32x4 o1 = *reinterpret_cast<const f32x4*>(&e_dst0[idx + 4]);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { v[r] += o0[r]; v[4 + r] += o1[r]; }
+                            }
+                            *reinterpret_cast<f32x4*>(&e_dst0[idx]) = (f32x4){v[0], v[1], v[2], v[3]};
+                            *reinterpret_cast<f32x4*>(&e_dst0[idx + 4]) = (f32x4){v[4], v[5], v[6], v[7]};
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) {
+                                if (t0 + r < e_Tlim) {
+                                    const long long idx = rowbase + t0 + r;
+                                    float x = v[r];
+                                    if (e_msk0 != nullptr) x *= (e_msk0[idx] > 0.f) ? 1.f : 0.2f;
+                                    if (accum) x += e_dst0[idx];
+                                    e_dst0[idx] = x;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int n = 0; n < NW; ++n) {
             const int ncol = n0 + n * 16 + li;
@@ -364,10 +429,13 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
 // launcher
 // ---------------------------------------------------------------------------------------
 bool conv_bf16_supported(const ConvArgs& a) {
-    if (a.flags & F_PHASE2) return false;
+    if ((a.flags & F_PHASE2) && !(a.ostride == 1 && a.dst1 == nullptr && a.loader == LOADER_DIRECT)) return false;
     if (a.C0 + a.C1 < 8) return false;                    // the 1-/2-channel audio input stays on the exact-fp32 kernel
     if (a.KW < 1 || a.KW > WUN_BF_KMAX) return false;
     if (a.Tin >= (1 << 23)) return false;
+    if (a.C1 > 0 && (a.C0 & 7) != 0) return false;         // an 8-channel group must not straddle the two sources
+    // the excerpt's tensor is addressed with 32-bit byte offsets
+    if ((long long)a.C0 * a.pitch0 * 4 >= (1ll << 31) || (long long)a.C1 * a.pitch1 * 4 >= (1ll << 31)) return false;
     return true;
 }
 
@@ -430,8 +498,10 @@ static hipError_t conv_bf16_launch_t(ConvArgs a, hipStream_t s) {
     const int planes = a.loader == LOADER_DEINT ? 2 : 1;
     const size_t lds = bf16_lds(a, TT, NT, NCK);
     if (lds > 160 * 1024 || ((planes * ROWS + 63) & ~63) * 4 * NCK > BfXit<MT>::v * 256) return hipErrorInvalidValue;
-    const int nTT = (a.Tout + TT - 1) / TT, nNT = (a.N + NT - 1) / NT;
-    const int tpw = bf16_tpw(a, TT, NT, NCK);
+    const bool phase2 = (a.flags & F_PHASE2) != 0;
+    if (phase2 && (NW % 2) != 0) return hipErrorInvalidValue;
+    const int nTT = (a.Tout + TT - 1) / TT, nNT = phase2 ? (a.N + NT / 2 - 1) / (NT / 2) : (a.N + NT - 1) / NT;
+    const int tpw = phase2 ? 1 : bf16_tpw(a, TT, NT, NCK);
     auto kern = tpw > 1 ? conv_bf16_kernel<MT, NW, true> : conv_bf16_kernel<MT, NW, false>;
     static size_t lds_allowed[2] = {64 * 1024, 64 * 1024};
     if (lds > lds_allowed[tpw > 1]) {
@@ -464,14 +534,17 @@ hipError_t launch_conv_bf16(const ConvArgs& a_in, hipStream_t s) {
     if (vec) a.flags |= F_VEC4;
     if (const char* e = getenv("WUN_BF_ABL")) a.flags |= atoi(e) << 16;      // diagnostic: skip phases of the kernel
     // tile: fewest padded columns among 64/48/32; rows by how many tiles the launch has
+    const bool phase2 = (a.flags & F_PHASE2) != 0;
     int bestnw = 4, bestpad = 1 << 30;
     const int cands[3] = {4, 3, 2};
     for (int i = 0; i < 3; ++i) {
-        const int ntile = cands[i] * 16;
+        if (phase2 && (cands[i] & 1)) continue;                // both phases of a channel live in one workgroup
+        const int ntile = phase2 ? cands[i] * 8 : cands[i] * 16;   // output channels per workgroup
         const int padded = ((a.N + ntile - 1) / ntile) * ntile;
         if (padded < bestpad) { bestpad = padded; bestnw = cands[i]; }
     }
-    const long long cols = (a.N + bestnw * 16 - 1) / (bestnw * 16);
+    const int chan_per_wg = phase2 ? bestnw * 8 : bestnw * 16;
+    const long long cols = (a.N + chan_per_wg - 1) / chan_per_wg;
     int mt = 4;
     while (mt > 1 && ((long long)((a.Tout + 64 * mt - 1) / (64 * mt)) * cols * a.B < 512 || a.Tout <= 32 * mt ||
                       bf16_lds(a, 64 * mt, bestnw * 16, 1) > 160 * 1024)) mt >>= 1;

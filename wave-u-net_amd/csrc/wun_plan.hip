@@ -343,11 +343,11 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
     p->bf16 = cfg->compute_dtype == 1;
     if (const char* e = getenv("WUN_BF16_MIN_ROWS")) p->bf16_min_rows = atoll(e);
     if (p->bf16) {
-        auto add_img = [&](int in_ws, long long src_off, int K, int Cc, int Nn) {
+        auto add_img = [&](int in_ws, long long src_off, int K, int Cc, int Nn, int slack = 0) {
             if (Cc < 8 || K < 1) return;
             PackDesc d;
             d.src_off = src_off; d.src_in_ws = in_ws; d.KW = K; d.C = Cc; d.N = Nn;
-            d.C8p = bf16_image_groups(Cc); d.Npad = (Nn + 63) / 64 * 64;
+            d.C8p = bf16_image_groups(Cc); d.Npad = (Nn + slack + 63) / 64 * 64;
             const long long items = (long long)K * d.C8p * d.Npad;
             d.dst_off = bump(w, items * 4);                     // 8 bf16 = 4 floats per item
             p->pack.push_back(d);
@@ -363,6 +363,8 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
             const ConvLayer& cl = p->down[i];
             add_img(1, cl.wt_full, cl.KW, cl.Cout, cl.Cin);
             if (!same) for (int ph = 0; ph < 2; ++ph) add_img(1, cl.wt_ph[ph], cl.Jp[ph], cl.Cout, cl.Cin);
+            // fused two-phase image: the transposed copy [J0][Cout][2][Cin] read as a [J0][Cout][2*Cin] matrix
+            if (!same) add_img(1, cl.wt_ph2, cl.J0, cl.Cout, 2 * cl.Cin, 32);   // (+32: a phase-1 column tile may overhang)
         }
         add_img(1, p->bott.wt_full, Kd, p->bott.Cout, p->bott.Cin);
         for (int j = 0; j < L; ++j) add_img(1, p->up[j].wt_full, Ku, p->up[j].Cout, p->up[j].Cin);
@@ -1121,7 +1123,10 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
                 f.Tin = d.t_dec; f.KW = cl.J0; f.kw_full = Kd; f.shift = cl.J0 - 1; f.W = ws + cl.wt_ph2;
                 f.N = f.N0 = d.cin; f.Tout = (d.t_in + 1) / 2; f.Tlim = d.t_in; f.flags = F_PHASE2;
                 set_dst0(f, ws, p->dz_dec[i - 1], 0, &p->dec[i - 1]);
-                if (!p->bf16 && (d.cin & 3) == 0 && f.Tout >= 256 && conv_natural_wgs_phase2(f) >= 256) {
+                // (bf16 mode: always fused when the channel count allows -- one launch, the gradient tile staged once,
+                //  contiguous 32-byte stores instead of two stride-2 scatter passes)
+                if ((d.cin & 3) == 0 && ((p->bf16 && conv_bf16_preferred(f, p->bf16_min_rows)) ||
+                                         (f.Tout >= 256 && conv_natural_wgs_phase2(f) >= 256))) {
                     HIP_TRY(conv_dispatch(p, f, ws + p->conv_part_off, p->conv_part_floats / 2, s));
                 } else {
                     for (int ph = 0; ph < 2; ++ph) {
@@ -1488,6 +1493,56 @@ extern "C" int wun_op_conv1d_bf16(const float* x, const float* w, const float* b
     hipError_t e = hipMemcpyAsync(dd, &d, sizeof(d), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = launch_pack_bf16(w, img, dd, 1, (long long)k * d.C8p * d.Npad, s);
     a.W = img; a.wb_c8p = d.C8p; a.wb_npad = d.Npad;
+    if (e == hipSuccess) e = launch_conv_bf16(a, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(dd);
+    HIP_TRY(e);
+    return WUN_OK;
+}
+
+// Input gradient of the bf16 speed mode as a single operator (wun_op_conv1d_dgrad semantics): stride 1 = the
+// bf16 conv on tap-flipped / transposed weights, stride 2 = the fused two-phase transposed conv (a lane owns 8
+// consecutive outputs).  scratch: >= wun_op_conv1d_dgrad_bf16_scratch floats.  Synchronises the stream.
+extern "C" int64_t wun_op_conv1d_dgrad_bf16_scratch(int cin, int cout, int k) {
+    const int64_t wt = 2ll * (k + 1) * cin * cout + 64;                                       // transposed fp32 copy
+    const int64_t img = (int64_t)(k + 1) * bf16_image_groups(cout) * ((2 * cin + 32 + 63) / 64 * 64) * 4 + 64;
+    return wt + img + 128;
+}
+
+extern "C" int wun_op_conv1d_dgrad_bf16(const float* dz, const float* w, float* dx, float* scratch, int batch, int cin,
+                                        int cout, int k, int t_in, int t_out, int stride, int pad_left, void* stream) {
+    if (!dz || !w || !dx || !scratch) return fail(WUN_ERR_INVALID, "null argument");
+    if (stride != 1 && stride != 2) return fail(WUN_ERR_UNSUPPORTED, "stride must be 1 or 2");
+    if (stride == 2 && (pad_left != 0 || (cin & 3) != 0)) return fail(WUN_ERR_UNSUPPORTED, "stride-2: pad_left 0 and cin % 4 == 0 only");
+    hipStream_t s = (hipStream_t)stream;
+    float* wt = (float*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
+    float* img = (float*)(((uintptr_t)(wt + 2ll * (k + 1) * cin * cout) + 255) & ~(uintptr_t)255);
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = batch; a.ostride = 1;
+    op_src(a, dz, cout, t_out);
+    a.Tin = t_out; a.N = a.N0 = cin;
+    a.dst0 = dx; a.obs0 = (long long)cin * t_in; a.opitch0 = t_in;
+    WtDesc d; d.src_off = 0; d.dst_off = 0; d.C = cin; d.N = cout;
+    PackDesc pd; pd.src_off = 0; pd.src_in_ws = 0; pd.dst_off = 0; pd.C = cout;
+    if (stride == 1) {
+        d.J = k; d.k_last = k - 1; d.k_step = 1; d.mode = 0;
+        a.shift = k - 1 - pad_left; a.KW = k; a.Tout = t_in;
+        pd.KW = k; pd.N = cin; pd.Npad = (cin + 63) / 64 * 64;
+    } else {
+        const int J0 = (k + 1) / 2;
+        d.J = J0; d.k_last = 2 * (J0 - 1); d.k_step = k; d.mode = 1;
+        a.KW = J0; a.kw_full = k; a.shift = J0 - 1; a.Tout = (t_in + 1) / 2; a.Tlim = t_in; a.flags = F_PHASE2;
+        pd.KW = J0; pd.N = 2 * cin; pd.Npad = (2 * cin + 32 + 63) / 64 * 64;
+    }
+    pd.C8p = bf16_image_groups(cout);
+    if (!conv_bf16_supported(a)) return fail(WUN_ERR_UNSUPPORTED, "shape not served by the bf16 kernel");
+    HIP_TRY(launch_make_wt_one(w, wt, d, s));
+    PackDesc* dd = nullptr;
+    HIP_TRY(hipMalloc((void**)&dd, sizeof(PackDesc)));
+    hipError_t e = hipMemcpyAsync(dd, &pd, sizeof(pd), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = launch_pack_bf16(wt, img, dd, 1, (long long)pd.KW * pd.C8p * pd.Npad, s);
+    a.W = img; a.wb_c8p = pd.C8p; a.wb_npad = pd.Npad;
     if (e == hipSuccess) e = launch_conv_bf16(a, s);
     (void)hipStreamSynchronize(s);
     (void)hipFree(dd);
