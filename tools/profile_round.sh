@@ -13,6 +13,7 @@ if [ "${PINNED:-1}" = 1 ] && [ -f $R/profiles/round2_tune_table.txt ]; then
 else
     [ "${KEEP_TUNE:-0}" = 1 ] || rm -f $WUN_TUNE_CACHE
 fi
+if [ "${ONLYCFGS:-0}" != 1 ]; then
 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_${tag}
@@ -38,6 +39,8 @@ cd $R
 python tools/pmc_report.py gpurun_out/${tag}_pmc_FETCH_SIZE.json gpurun_out/${tag}_pmc_WRITE_SIZE.json gpurun_out/${tag}_pmc_mfma.json \
     gpurun_out/${tag}_pmc_traffic.json gpurun_out/${tag}_pmc_mfma_util.txt "$tag" $WUN_TUNE_CACHE
 tail -1 gpurun_out/${tag}_bench.json | cut -c1-400
+fi
+cd $R
 # the other BASELINE.json configs, fp32 and the bf16 speed mode (named-config benches; no CPU baseline)
 if [ "${CFGS:-1}" = 1 ]; then
     unset WUN_TUNE_CACHE
