@@ -679,9 +679,6 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvArgs a, i
         const int q = (int)(i % TP4) * 4;
         const long long bn = i / TP4;
         const int ncol = (int)(bn % a.N), b = (int)(bn / a.N);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        const float* pp = a.part + bn * TP + q;
-        for (int ks = 0; ks < ksplit; ++ks) v += *reinterpret_cast<const f32x4*>(pp + (long long)ks * sstride);
         const float bvv = (a.bias != nullptr) ? a.bias[ncol] : 0.f;
         float* dst; const float* msk; long long rowbase;
         if (ncol < a.N0) {
@@ -691,19 +688,52 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvArgs a, i
             rowbase = (long long)b * a.obs1 + (long long)(ncol - a.N0) * a.opitch1 + a.ooff1;
             dst = a.dst1; msk = a.msk1;
         }
+        // mask / old values of the vector path are requested before the partials (independent loads)
+        const bool vpath = vec && q + 3 < a.Tout;
+        f32x4 mk = {1.f, 1.f, 1.f, 1.f}, old = {0.f, 0.f, 0.f, 0.f};
+        if (vpath && msk != nullptr) mk = *reinterpret_cast<const f32x4*>(&msk[rowbase + q]);
+        if (vpath && accum) old = *reinterpret_cast<const f32x4*>(&dst[rowbase + q]);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const float* pp = a.part + bn * TP + q;
+        // the loads of a batch are all in flight before the first add (a load + wait per split made this kernel
+        // ksplit memory latencies long: 12-16 us on the critical path of every deep level); the sum order is unchanged
+        int ks = 0;
+        for (; ks + 8 <= ksplit; ks += 8) {
+            f32x4 t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = *reinterpret_cast<const f32x4*>(pp + (long long)(ks + j) * sstride);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v += t[j];
+        }
+        if (ks + 4 <= ksplit) {
+            f32x4 t[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = *reinterpret_cast<const f32x4*>(pp + (long long)(ks + j) * sstride);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v += t[j];
+            ks += 4;
+        }
+        {
+            f32x4 t[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                t[j] = (ks + j < ksplit) ? *reinterpret_cast<const f32x4*>(pp + (long long)(ks + j) * sstride) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (ks + j < ksplit) v += t[j];
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             v[r] += bvv;
             if (lrelu) v[r] = fmaxf(0.2f * v[r], v[r]);
         }
-        if (vec && q + 3 < a.Tout) {
+        if (vpath) {
             const long long idx = rowbase + q;
             if (msk != nullptr) {
-                const f32x4 mk = *reinterpret_cast<const f32x4*>(&msk[idx]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] *= (mk[r] > 0.f) ? 1.f : 0.2f;
             }
-            if (accum) v += *reinterpret_cast<const f32x4*>(&dst[idx]);
+            if (accum) v += old;
             *reinterpret_cast<f32x4*>(&dst[idx]) = v;
             if (a.dec != nullptr && ncol < a.N0) {
                 float* decrow = a.dec + (long long)b * a.decbs + (long long)ncol * a.decpitch;
@@ -1383,7 +1413,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradReduceArgs a) {
     if (live) {
         const f32x4* p = reinterpret_cast<const f32x4*>(a.partial) + gv;
         const long long sstride = ntile * tile_v;
-        for (int k = sl; k < a.nsplit; k += SL) sum += p[(long long)k * sstride];
+        // batches of independent loads, summed in split order (a load + wait per split serialised nsplit / SL
+        // memory latencies: 58 us for 922 splits)
+        int k = sl;
+        for (; k + 7 * SL < a.nsplit; k += 8 * SL) {
+            f32x4 t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = p[(long long)(k + j * SL) * sstride];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += t[j];
+        }
+        for (; k < a.nsplit; k += SL) sum += p[(long long)k * sstride];
     }
     if constexpr (SL > 1) {
         red[threadIdx.x] = sum;

@@ -527,13 +527,36 @@ static HeadArgs head_args(const wun_plan* p, const float* params, float* ws, flo
 // ---------------------------------------------------------------------------------------
 // two-stream helpers
 // ---------------------------------------------------------------------------------------
+// Flags of the plan's cross-stream events.  They only order kernels of ONE device against each other: the kernel
+// packets' own end-of-kernel release / start-of-kernel acquire (agent scope, needed between any two dependent kernels
+// on a part whose 8 L2s are not coherent) already make the data visible, so the event itself carries no system-scope
+// fence (hipEventDisableSystemFence; host-side consumers synchronise through the caller's stream, never through
+// these events).  A/B with pinned tilings: 9.25 -> 9.14 ms per step; the whole GPU suite (bit-exact determinism,
+// B=16 vs oracle) passes in both modes.  WUN_EVENT_SCOPE=system|device: fall-back switch.
+static unsigned event_flags() {
+    static const unsigned f = [] {
+        const char* e = getenv("WUN_EVENT_SCOPE");
+        if (e && e[0] == 's') return (unsigned)hipEventDisableTiming;
+        if (e && e[0] == 'd') return (unsigned)(hipEventDisableTiming | hipEventReleaseToDevice);
+        return (unsigned)(hipEventDisableTiming | hipEventDisableSystemFence);
+    }();
+    return f;
+}
+
 static int side_init(const wun_plan* p) {
     if (p->side != nullptr) return WUN_OK;
     if (getenv("WUN_SINGLE_STREAM") != nullptr) return WUN_OK;      // debugging: everything on one stream
-    HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
-    if (getenv("WUN_TWO_STREAMS") == nullptr) HIP_TRY(hipStreamCreateWithFlags(&p->side2, hipStreamNonBlocking));
+    // The side streams carry the off-critical-path work (weight gradients, deferred skip-window convs): lowest queue
+    // priority, so their workgroups fill the drain of the dependent chain on the caller's stream instead of sharing the
+    // CUs with it (A/B, pinned tilings: 9.32 -> 9.21 ms per step; "high" 9.39).  WUN_SIDE_PRIO=normal|high: experiment switch.
+    int least = 0, greatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    int prio = least;
+    if (const char* e = getenv("WUN_SIDE_PRIO")) prio = (e[0] == 'l') ? least : (e[0] == 'h') ? greatest : 0;
+    HIP_TRY(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, prio));
+    if (getenv("WUN_TWO_STREAMS") == nullptr) HIP_TRY(hipStreamCreateWithPriority(&p->side2, hipStreamNonBlocking, prio));
     p->events.resize(160);
-    for (auto& e : p->events) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : p->events) HIP_TRY(hipEventCreateWithFlags(&e, event_flags()));
     return WUN_OK;
 }
 // `to` waits for everything issued so far on `from`
@@ -634,7 +657,7 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
     if (training && !p->wt.empty() && p->dev_wt && s2 != s) {
         // the backward pass will need tap-flipped / transposed copies of every kernel: make them now,
         // beside the forward convs (they depend on the parameters only)
-        if (!p->wt_ev) HIP_TRY(hipEventCreateWithFlags(&p->wt_ev, hipEventDisableTiming));
+        if (!p->wt_ev) HIP_TRY(hipEventCreateWithFlags(&p->wt_ev, event_flags()));
         if ((rc0 = stream_dep(p, s, s2))) return rc0;
         HIP_TRY(launch_make_wt(params, ws, p->dev_wt, (int)p->wt.size(), p->wt_max, s2));
         if (p->bf16)
@@ -658,7 +681,7 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
         if (defer_below > 0 && p->skip_ev.size() < (size_t)L) {
             p->skip_ev.resize(L, nullptr);
             for (auto& e : p->skip_ev)
-                if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                if (!e) HIP_TRY(hipEventCreateWithFlags(&e, event_flags()));
         }
     }
     std::vector<ConvArgs> deferred((size_t)defer_below);
@@ -678,8 +701,10 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
             a.dec = ws + p->dec[i].off; a.decbs = p->dec[i].bs; a.decpitch = p->dec[i].pitch;
             HIP_TRY(conv_dispatch(p, a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
         } else {
-            // x (written on `s`) is ready for both convs of this level: the side stream may start
-            if ((rc0 = stream_dep(p, s, s2))) return rc0;
+            // x (written on `s`) is ready for both convs of this level: the side stream may start.  (Levels whose
+            // window conv is deferred queue nothing on s2: no event -- every record / wait on the caller's stream is a
+            // barrier packet that holds the dependent chain for ~7 us.)
+            if (i >= defer_below && (rc0 = stream_dep(p, s, s2))) return rc0;
             // stride-2 conv straight into the decimated stream (odd outputs are never observed)
             ConvArgs a = conv_base(p);
             set_src0(a, ws, *x, 0, d.cin);
@@ -769,9 +794,10 @@ static bool wgrad_common_geom(WgradArgs* parts, int nparts, int mtw, int nw) {
 }
 
 static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const ConvLayer& cl, float* ws,
-                     float* grads, hipStream_t main, hipStream_t s) {
+                     float* grads, hipStream_t main, hipStream_t s, bool dep = true) {
     // everything this weight gradient reads (dz, activations) has been issued on `main`
-    {
+    // (dep == false: the caller already made `s` wait -- one event for a batch of weight gradients)
+    if (dep) {
         int rcd = stream_dep(p, main, s);
         if (rcd) return rcd;
     }
@@ -950,6 +976,42 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
         }
         return sig.ready(floor, s2);
     };
+    // Every event recorded on the caller's stream is a barrier packet that holds the dependent chain for ~7 us
+    // (rocprofv3 timeline), a third of a deep level's kernel.  The weight gradients of the levels with few positions
+    // CAN therefore be queued in batches (one event for up to WUN_WG_BATCH levels, both side streams wait on it; the
+    // FLOP-heavy levels always flush at once) -- measured: 41 -> 26 stalls per step, but the delayed weight
+    // gradients lengthen the tail after the last input gradient by more (9.12 ms with batches of 1, 9.19-9.23 with
+    // 2-5), so the default stays one event per level.
+    struct PendingWgrad { WgradArgs w[2]; int n; const ConvLayer* cl; };
+    std::vector<PendingWgrad> pend;
+    static const int wg_batch = getenv("WUN_WG_BATCH") ? atoi(getenv("WUN_WG_BATCH")) : 1;
+    static const long long wg_batch_rows = getenv("WUN_WG_BATCH_ROWS") ? atoll(getenv("WUN_WG_BATCH_ROWS")) : 16384;
+    auto flush_wgrads = [&]() -> int {
+        if (pend.empty()) return WUN_OK;
+        if (s2 != s) {
+            hipEvent_t e = p->events[p->ev_next++ % p->events.size()];
+            HIP_TRY(hipEventRecord(e, s));
+            HIP_TRY(hipStreamWaitEvent(s2, e, 0));
+            if (s3 != s2) HIP_TRY(hipStreamWaitEvent(s3, e, 0));
+        }
+        for (auto& q : pend) {
+            int rcq = run_wgrad(p, q.w, q.n, *q.cl, ws, grads, s, wstream(), false);
+            if (rcq) return rcq;
+            if ((rcq = ready2(q.cl->woff))) return rcq;
+        }
+        pend.clear();
+        return WUN_OK;
+    };
+    auto submit_wgrad = [&](const WgradArgs* w, int n, const ConvLayer& cl) -> int {
+        PendingWgrad q;
+        for (int k = 0; k < n; ++k) q.w[k] = w[k];
+        q.n = n; q.cl = &cl;
+        pend.push_back(q);
+        long long rows = 0;
+        for (int k = 0; k < n; ++k) rows += (long long)w[k].B * w[k].Tq;
+        if (rows >= wg_batch_rows || (int)pend.size() >= wg_batch) return flush_wgrads();
+        return WUN_OK;
+    };
 
     if (p->wt_ready) {
         HIP_TRY(hipStreamWaitEvent(s, p->wt_ev, 0));       // made during the forward pass
@@ -1006,10 +1068,9 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
             wset_src1(w, ws, p->ups[j], 0, u.c_cur);
             w.Tin = u.t_up; w.shift = padU; w.KW = Ku;
             wset_dz(w, ws + p->dz_upo[j].off, p->dz_upo[j].bs, p->dz_upo[j].pitch, u.cout, u.t_conv);
-            if ((rc = run_wgrad(p, &w, 1, p->up[j], ws, grads, s, wstream()))) return rc;
             // (interp_j, written on `s` by the previous level's upsample_bwd, sits above up[j] in
-            // the arena; run_wgrad made s2 wait for everything issued on `s` so far)
-            if ((rc = ready2(p->up[j].woff))) return rc;
+            // the arena; the flush makes the side streams wait for everything issued on `s` so far)
+            if ((rc = submit_wgrad(&w, 1, p->up[j]))) return rc;
         }
         {
             ConvArgs a = conv_base(p);
@@ -1041,8 +1102,7 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
         wset_src0(w, ws, p->dec[L - 1], 0, p->bott.Cin);
         w.Tin = p->t_b_in; w.shift = padD; w.KW = Kd;
         wset_dz(w, ws + p->dz_bott.off, p->dz_bott.bs, p->dz_bott.pitch, p->c_b, p->t_b);
-        if ((rc = run_wgrad(p, &w, 1, p->bott, ws, grads, s, wstream()))) return rc;
-        if ((rc = ready2(p->bott.woff))) return rc;
+        if ((rc = submit_wgrad(&w, 1, p->bott))) return rc;
         ConvArgs a = conv_base(p);
         set_src0(a, ws, p->dz_bott, 0, p->c_b);
         a.Tin = p->t_b; a.shift = Kd - 1 - padD; a.W = ws + p->bott.wt_full; a.KW = Kd;
@@ -1083,6 +1143,7 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
             narrow = narrow_wgrad_supported(nw[0]) && (same || narrow_wgrad_supported(nw[1])) && getenv("WUN_NO_NARROW") == nullptr && getenv("WUN_NO_NARROW_DOWN0") == nullptr;
         }
         if (narrow) {
+            if ((rc = flush_wgrads())) return rc;
             const long long woff[4] = {cl.woff, 0, 0, 0}, boff[4] = {cl.boff, 0, 0, 0};
             if ((rc = run_narrow_wgrad(p, nw, same ? 1 : 2, woff, boff, ws, grads, s, wstream()))) return rc;
             if ((rc = ready2(cl.woff))) return rc;
@@ -1091,8 +1152,7 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
             wset_src0(w, ws, x, 0, d.cin);
             w.Tin = d.t_in; w.shift = padD; w.KW = Kd;
             wset_dz(w, ws + p->dz_skip[i].off, p->dz_skip[i].bs, p->dz_skip[i].pitch, d.cout, d.t_conv);
-            if ((rc = run_wgrad(p, &w, 1, cl, ws, grads, s, wstream()))) return rc;
-            if ((rc = ready2(cl.woff))) return rc;
+            if ((rc = submit_wgrad(&w, 1, cl))) return rc;
             if (i > 0) {
                 ConvArgs a = conv_base(p);
                 set_src0(a, ws, p->dz_skip[i], 0, d.cout);
@@ -1112,8 +1172,7 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
             wset_src0(w[1], ws, x, d.cs, d.cin);
             w[1].Tin = d.tc + Kd - 1; w[1].shift = 0; w[1].KW = Kd;
             wset_dz(w[1], ws + p->dz_skip[i].off, p->dz_skip[i].bs, p->dz_skip[i].pitch, d.cout, d.tc);
-            if ((rc = run_wgrad(p, w, 2, cl, ws, grads, s, wstream()))) return rc;
-            if ((rc = ready2(cl.woff))) return rc;
+            if ((rc = submit_wgrad(w, 2, cl))) return rc;
             if (i > 0) {
                 // transposed stride-2 conv: both output phases fused in one launch (a lane owns 8
                 // consecutive outputs) when the launch fills the chip, else one phase at a time
@@ -1149,6 +1208,7 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
             }
         }
     }
+    if ((rc = flush_wgrads())) return rc;
     if ((rc = stream_dep(p, s3, s))) return rc;
     if ((rc = stream_dep(p, s2, s))) return rc;      // all gradients are complete w.r.t. `stream`
     if ((rc = sig.ready(0, s))) return rc;           // any bucket not yet signalled (e.g. single-stream mode)
