@@ -161,8 +161,12 @@ BF16_WGRAD_CASES = [
     (3, 64, 72, 15, 23, 1, 0, False),
     (4, 120, 144, 15, 1100, 2, 0, False),
     (4, 168, 72, 5, 2053, 1, 0, False),
+    (2, 9, 16, 7, 150, 1, 3, True),              # odd channel count: half-filled channel pair and block
+    (2, 104, 40, 3, 333, 1, 1, True),            # 5 channel blocks per workgroup (3 taps)
+    (2, 32, 24, 15, 131, 2, 0, False),
 ]
-WGRAD_GEOMS = [(0, 0)] + [(m, n) for m in (1, 2, 4) for n in (1, 2, 3, 4, 5)] + [(6, 1), (6, 2), (6, 3)]
+# (tiles per wave, column tiles) of the bf16 kernel: 4 x {1..4}, 8 x {1..3}; (0, 0) = heuristic
+WGRAD_GEOMS = [(0, 0)] + [(4, n) for n in (1, 2, 3, 4)] + [(8, n) for n in (1, 2, 3)]
 
 
 @pytest.mark.parametrize("case", BF16_WGRAD_CASES, ids=[str(c) for c in BF16_WGRAD_CASES])

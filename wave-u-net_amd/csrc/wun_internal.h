@@ -76,11 +76,17 @@ struct WgradArgs {
     int bf16;        // speed mode: operands rounded to bf16 in LDS, v_mfma_f32_16x16x32_bf16 (wun_wgrad_bf16.hip)
 };
 
-// tile geometry of a weight-gradient launch (shared by the exact-fp32 and the bf16 kernel: same tiles, same
-// tile-major partial layout, same split reduction)
+// tile geometry of an exact-fp32 weight-gradient launch
 struct WgradGeom { int MTW, NW, nMG, nNG, TK, XP, ZP, nChMax, ONESP, XW4; size_t lds; };
 WgradGeom wgrad_geom(const WgradArgs& a);
+// bf16 speed mode (wun_wgrad_bf16.hip): own tiling -- MFMA rows = 16 input channels of one tap; a workgroup holds
+// 4*MTW slots = NCB channel blocks x KW taps + the bias slot
+struct WgradBfGeom { int MTW, NW, NCB, nCB, nMG, nNG, TK, XW4, XROWS, ZPe; size_t lds; };
+bool wgrad_bf16_supported(const WgradArgs& a);
+WgradBfGeom wgrad_bf16_geom(const WgradArgs& a);
 hipError_t launch_wgrad_bf16(const WgradArgs& a, hipStream_t s);
+hipError_t launch_wgrad_bf16_reduce(const WgradArgs& a, const float* partial, int nsplit, float* out_w, float* out_b,
+                                    hipStream_t s);
 
 // Narrow weight gradient (wun_narrow.hip): audio-input conv / output head.  Input = virtual concat of two
 // NCW sources as in WgradArgs; dz row n = (s, c), s = n / Nper, at dz + s*zss + b*dzbs + c*dzpitch.

@@ -1498,16 +1498,19 @@ WgradGeom wgrad_geom(const WgradArgs& a) {
     return g;
 }
 
+// (bf16 speed mode: the same questions answered for the bf16 kernel's own tiling)
 int wgrad_max_units(const WgradArgs& a) {
-    WgradGeom g = wgrad_geom(a);
-    return a.B * ((a.Tq + g.TK - 1) / g.TK);
+    const int TK = a.bf16 ? wgrad_bf16_geom(a).TK : wgrad_geom(a).TK;
+    return a.B * ((a.Tq + TK - 1) / TK);
 }
 
 int wgrad_pick_nsplit(const WgradArgs& a) {
-    WgradGeom g = wgrad_geom(a);
-    const int nQT = (a.Tq + g.TK - 1) / g.TK;
+    int TK, nMG, nNG;
+    if (a.bf16) { const WgradBfGeom b = wgrad_bf16_geom(a); TK = b.TK; nMG = b.nMG; nNG = b.nNG; }
+    else { const WgradGeom f = wgrad_geom(a); TK = f.TK; nMG = f.nMG; nNG = f.nNG; }
+    const int nQT = (a.Tq + TK - 1) / TK;
     const long long units = (long long)a.B * nQT;
-    const long long per = (long long)g.nMG * g.nNG;
+    const long long per = (long long)nMG * nNG;
     long long ns = (1024 + per - 1) / per;
     // big weight blocks: every split writes+reads the whole block once, so aim lower (512 workgroups)
     const long long blk = (long long)a.KW * (a.C0 + a.C1) * a.N;
@@ -1568,12 +1571,14 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
 }
 
 void wgrad_resolved_geom(const WgradArgs& a, int& mtw, int& nw) {
+    if (a.bf16) { const WgradBfGeom b = wgrad_bf16_geom(a); mtw = b.MTW; nw = b.NW; return; }
     const WgradGeom g = wgrad_geom(a);
     mtw = g.MTW; nw = g.NW;
 }
 
 // floats one split of this weight gradient occupies in the tile-major partial buffer
 long long wgrad_partial_floats(const WgradArgs& a) {
+    if (a.bf16) { const WgradBfGeom b = wgrad_bf16_geom(a); return (long long)b.nMG * b.nNG * (4 * b.MTW * 16) * (b.NW * 16); }
     const WgradGeom g = wgrad_geom(a);
     return (long long)g.nMG * g.nNG * (4 * g.MTW * 16) * (g.NW * 16);
 }
@@ -1581,6 +1586,7 @@ long long wgrad_partial_floats(const WgradArgs& a) {
 // partial: `nsplit` consecutive splits written by launch_wgrad calls that share `a`'s tile geometry
 hipError_t launch_wgrad_reduce(const WgradArgs& a, const float* partial, int nsplit, float* out_w, float* out_b,
                                hipStream_t s) {
+    if (a.bf16) return launch_wgrad_bf16_reduce(a, partial, nsplit, out_w, out_b, s);
     const WgradGeom g = wgrad_geom(a);
     WgradReduceArgs r;
     r.partial = partial; r.out_w = out_w; r.out_b = out_b;

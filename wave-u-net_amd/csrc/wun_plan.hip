@@ -373,7 +373,9 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
     // ---- wgrad partial buffer: max over layers of (total splits) * (kernel + bias floats) ----
     long long pmax = 0;
     // floats per split in the tile-major partial buffer, worst-case tile padding (384 rows x 80 columns)
-    auto blockf = [](const ConvLayer& cl) { return ((long long)cl.KW * cl.Cin + 1 + 384) * (cl.Cout + 80); };
+    // (bf16 speed mode: rows come in slots of 16 channels x 1 tap, up to 32 slots per row group)
+    const long long rowpad = p->bf16 ? 1024 : 384;
+    auto blockf = [rowpad](const ConvLayer& cl) { return ((long long)cl.KW * (cl.Cin + 15) + 1 + rowpad) * (cl.Cout + 80); };
     for (int i = 0; i < L; ++i) {
         const DownShape& d = p->dsh[i];
         long long ns;
@@ -803,7 +805,7 @@ static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const Conv
     }
     // bf16 speed mode: operands rounded to bf16 in LDS (same tiles, same partial layout); launches with few
     // positions are latency-bound and stay exact fp32
-    if (p->bf16 && parts[0].C0 + parts[0].C1 >= 8) {
+    if (p->bf16 && wgrad_bf16_supported(parts[0])) {
         long long rows = 0;
         for (int i = 0; i < nparts; ++i) rows += (long long)parts[i].B * parts[i].Tq;
         if (rows >= p->bf16_min_rows)
@@ -820,7 +822,7 @@ static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const Conv
         int m, n;
         parts[0].force_mtw = parts[0].force_nw = 0;
         wgrad_resolved_geom(parts[0], m, n);
-        while (!wgrad_common_geom(parts, nparts, m, n) && m > 1) m = m == 6 ? 4 : m / 2;
+        while (!wgrad_common_geom(parts, nparts, m, n) && m > 1) m = m == 6 ? 4 : m / 2;   // (bf16: 8 -> 4)
     }
     for (int i = 0; i < nparts; ++i) parts[i].nsplit = wgrad_pick_nsplit(parts[i]);
 
@@ -848,9 +850,9 @@ static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const Conv
         float best = time_launch(p, s, [&]() { return run(parts); });
         const float base = best;
         WgradChoice bc{0, 0, {0, 0}};
-        static const int mtws[] = {6, 4, 2, 1};
+        static const int mtws[] = {8, 6, 4, 2, 1};         // (8: bf16 kernel only; 6, 2, 1: exact-fp32 kernel only)
         WgradArgs g[2];
-        for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < 5; ++mi)
             for (int nw = 5; nw >= 1; --nw) {
                 if (nw > 3 && (mtws[mi] == 6 || parts[0].N <= 48)) continue;
                 for (int i = 0; i < nparts; ++i) g[i] = parts[i];
@@ -883,7 +885,7 @@ static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const Conv
     }
     if (p->tune_mode >= 1 && idx < p->wg_bwd.size() && p->wg_bwd[idx].nsplit[0] > 0) {
         const WgradChoice& c = p->wg_bwd[idx];
-        bool ok = (c.mtw == 1 || c.mtw == 2 || c.mtw == 4 || c.mtw == 6) && c.nw >= 1 && c.nw <= 5;
+        bool ok = (c.mtw == 1 || c.mtw == 2 || c.mtw == 4 || c.mtw == 6 || c.mtw == 8) && c.nw >= 1 && c.nw <= 5;
         for (int i = 0; ok && i < nparts; ++i) ok = c.nsplit[i] >= 1;
         WgradArgs g[2];
         for (int i = 0; i < nparts; ++i) g[i] = parts[i];
@@ -1384,6 +1386,7 @@ static WgradArgs op_wgrad_args(const float* x, const float* dz, int batch, int c
 // split partials of one loader kind under the current (possibly forced) geometry / split count
 static long long op_wgrad_part_floats(int batch, int cin, int cout, int k, int t_out, int loader) {
     WgradArgs a = wgrad_shape_only(batch, cin, 0, k, loader, cout, t_out);
+    a.bf16 = (g_op_wg_bf16 && wgrad_bf16_supported(a)) ? 1 : 0;
     if (g_op_wg_mtw > 0) { a.force_mtw = g_op_wg_mtw; a.force_nw = g_op_wg_nw; }
     long long ns = wgrad_pick_nsplit(a);
     if (g_op_wg_nsplit > 0) ns = std::min(g_op_wg_nsplit, wgrad_max_units(a));
@@ -1416,6 +1419,8 @@ extern "C" int wun_op_conv1d_wgrad(const float* x, const float* dz, float* dw, f
     HIP_TRY(hipMemcpy2DAsync(zs, (size_t)zp * 4, dz, (size_t)t_out * 4, (size_t)t_out * 4, (size_t)batch * cout,
                              hipMemcpyDeviceToDevice, s));
     WgradArgs w = op_wgrad_args(xs, zs, batch, cin, cout, k, t_in, t_out, stride, pad_left, xp, zp);
+    if (g_op_wg_bf16 && !wgrad_bf16_supported(w)) return fail(WUN_ERR_UNSUPPORTED, "shape not served by the bf16 weight-gradient kernel");
+    w.bf16 = g_op_wg_bf16;
     if (g_op_wg_mtw > 0) {
         w.force_mtw = g_op_wg_mtw; w.force_nw = g_op_wg_nw;
         int m, n;
@@ -1423,7 +1428,6 @@ extern "C" int wun_op_conv1d_wgrad(const float* x, const float* dz, float* dw, f
         if (m != g_op_wg_mtw || n != g_op_wg_nw)
             return fail(WUN_ERR_UNSUPPORTED, "forced weight-gradient tile geometry is not available for this shape");
     }
-    w.bf16 = g_op_wg_bf16;
     w.nsplit = wgrad_pick_nsplit(w);
     if (g_op_wg_nsplit > 0) {
         w.nsplit = std::min(g_op_wg_nsplit, wgrad_max_units(w));

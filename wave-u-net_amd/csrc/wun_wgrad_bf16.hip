@@ -1,19 +1,28 @@
 // gfx950 bf16-MFMA speed mode of the weight / bias gradient.
 //
-//   D[(cin,tap) 16][cout 16] += A[(cin,tap)][q] * B[q][cout]   on v_mfma_f32_16x16x32_bf16 (fp32 accumulate),
-//   k = output position q, 32 positions per MFMA.
+//   dW[tap][cin][cout] = sum over (excerpt, q) of X[cin][q*stride + tap] * dZ[cout][q]
+//   on v_mfma_f32_16x16x32_bf16 (fp32 accumulate): MFMA rows = 16 input channels of ONE tap, columns = 16 output
+//   channels, k = 32 output positions.
 //
-// Same decomposition as the exact-fp32 kernel (wun_kernels.hip, wgrad_mfma_kernel): same (row group,
-// column group, split) tiles, same units of <= 128 positions, same tile-major split partials summed in
-// fixed order by wgrad_reduce_kernel, an all-ones A row for the bias gradient.  What differs:
-//   * the input rows and the dz rows are rounded to bf16 (nearest-even) when they are written to LDS
-//     (HBM tensors stay fp32); the accumulators and the partials are fp32;
-//   * a B fragment is one aligned 16-byte LDS read (8 consecutive positions of one dz row; row pitch
-//     2*TK + 32 bytes keeps the ds_read_b128 lane groups conflict-free);
-//   * an A fragment is 8 consecutive positions of input row `cin` starting at tap + alignment shift, i.e.
-//     at an arbitrary 2-byte offset: eight 16-bit LDS reads (the price of serving all 15 taps from ONE
-//     staged copy of the row; lanes of one channel read neighbouring halves of the same dwords, which
-//     the LDS broadcasts).
+// The reduction runs over POSITIONS, and the A operand of tap j is the input row shifted by j samples: in a
+// channel-major LDS image that is 8 consecutive bf16 at an arbitrary 2-byte offset (the first version of this
+// kernel assembled every A fragment from eight 16-bit LDS reads and was LDS-issue-bound at 9-17 % of the bf16
+// MFMA peak).  Here the input tile is staged POSITION-major -- Xs[channel block][position][16 channels], 32-byte
+// rows -- and read with gfx950's transposing LDS read (ds_read_b64_tr_b16: a 16-lane group fetches a
+// [4 positions][16 channels] block and every lane receives the 4 positions of its channel): the tap shift is a ROW
+// offset, an A fragment is two such reads (4 LDS cycles, like the aligned B fragment), and one staged tile serves
+// all taps.  Lane group g of a k-step holds positions {4g..4g+3, 16+4g..16+4g+3} in BOTH operands (k is a
+// summation index, any consistent assignment works), which makes the A reads of a wave cover 512 contiguous bytes
+// (no bank conflicts) and the B fragment two 8-byte reads of a dz row.
+//
+// Workgroup = 4 waves x MTW row tiles = 4*MTW slots: slot t < NCB*K is (channel block t / K, tap t % K) with
+// NCB = (4*MTW - 1) / K channel blocks per workgroup, the last slot is the bias gradient (an all-ones A operand in
+// registers; row group 0 only).  Columns: NW tiles of 16 output channels shared by all waves.  The position axis is
+// split over workgroups in units of TK <= 128 positions of one excerpt; every workgroup writes its raw tiles to the
+// tile-major partial buffer and wgrad_bf16_reduce_kernel sums the splits in fixed order (deterministic, no atomics).
+// HBM tensors stay fp32: the operands are rounded to bf16 (nearest even, v_cvt_pk_bf16_f32) when they are written
+// to LDS.  Staging writes are rotated per position group so that the 32-byte rows of 4 neighbouring groups land on
+// different banks.
 #include "wun_internal.h"
 
 #include <cstdio>
@@ -24,6 +33,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 typedef __bf16 wb_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float wb_f32x2 __attribute__((ext_vector_type(2)));
@@ -38,61 +48,72 @@ __device__ __forceinline__ int wb_xcd_block(int bid, int grid) {
     return xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
 }
 
-#define WUN_WGB_XIT 8      // float4 X loads per thread and unit (same staging bound as the fp32 kernel)
+// 4 positions x 16 channels block -> the 4 positions of this lane's channel (see the header)
+__device__ __forceinline__ u32x2 wb_tr_read(const unsigned short* p) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p));
+}
 
-// XPe / ZPe: row pitches in bf16 ELEMENTS; ONESPe: length of the all-ones row
+#define WUN_WGB_XITP 4     // staged (channel pair, 4 positions) items per thread and unit: 2 float4 loads each
+
+struct WgBfK { int NCB, nCB, nMG, nNG, TK, XW4, XROWS, ZPe; };
+
 template <int MTW, int NW>
-__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradArgs a, int nMG, int nNG, int TK, int XPe, int ZPe,
-                                                            int nChMax, int ONESPe, int XW4) {
-    extern __shared__ __attribute__((aligned(16))) unsigned short wlds[];
-    constexpr int MG = 4 * MTW * 16;
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a, WgBfK g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short wl[];
     constexpr int NG = NW * 16;
+    constexpr int SLOTS = 4 * MTW;
     constexpr int ZIT = (NG * 32 + 255) / 256;          // TK/4 <= 32 float4 per dz row
     const bool deint = (a.loader == LOADER_DEINT);
     const int planes = deint ? 2 : 1;
-    unsigned short* Xs = wlds + ONESPe;
-    unsigned short* Zs = Xs + ((nChMax * planes * XPe + 7) & ~7);      // 16-byte aligned
+    const int xsub = planes * g.XROWS * 16;             // elements of one channel block's image (multiple of 64)
+    // wl[0, 512): 32 rows x 16 of bf16 1.0 -- the A operand of the bias slot (and of idle slots, whose results are
+    // discarded): every slot of the MFMA loop is the same pair of reads, so the loop has no branches and the
+    // compiler can issue all LDS reads of a k-step ahead of its MFMAs
+    unsigned short* Xs = wl + 512;
+    unsigned short* Zs = Xs + g.NCB * xsub + 64;           // (+ a trash row for staged positions before the image start)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int li = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bid = wb_xcd_block((int)blockIdx.x, (int)gridDim.x);
-    const int ng = bid % nNG; bid /= nNG;
-    const int mg = bid % nMG;
-    const int split = bid / nMG;
-
+    const int ng = bid % g.nNG; bid /= g.nNG;
+    const int mg = bid % g.nMG;
+    const int split = bid / g.nMG;
+    const int cb0 = mg * g.NCB;
     const int Ctot = a.C0 + a.C1;
-    const int Mtot = Ctot * a.KW;                      // row Mtot is the bias (all-ones) row
-    const int rlo = mg * MG;
-    const int cLo = rlo / a.KW;
-    int cHi = (rlo + MG - 1) / a.KW;
-    if (cHi > Ctot - 1) cHi = Ctot - 1;
-    const int nCh = cHi - cLo + 1;                     // may be <= 0 (bias-only group)
+    const int K = a.KW;
 
+    // alignment of the staged window: vector loads start at a multiple of 4 floats of the source row
     const int delta0 = ((a.off0 - a.shift) % 4 + 4) % 4;
     const int delta1 = ((a.off1 - a.shift) % 4 + 4) % 4;
 
-    int rowoff[MTW];                                   // element offset of this lane's A row in wlds (0 = ones row)
-    int nact = 0;
+    // per slot of this wave: LDS element offset of this lane's transposing read (row 4*lg + (li >> 2) of the tap's
+    // first k-step, columns 4*(li & 3)..) and its advance per k-step (0 for the ones block); kind: 0 real, 1 bias, 2 idle
+    int abase[MTW], astep[MTW], kind[MTW];
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
-        const int rt = rlo + (wave * MTW + mt) * 16;
-        if (rt <= Mtot) nact = mt + 1;
-        const int r = rt + li;
-        int off = 0;
-        if (r < Mtot) {
-            const int c = r / a.KW, k = r - c * a.KW;
-            const int kd = k + (c < a.C0 ? delta0 : delta1);
-            off = ONESPe + (c - cLo) * planes * XPe + (deint ? ((kd & 1) * XPe + (kd >> 1)) : kd);
+        const int slot = wave * MTW + mt;
+        const int lane_off = (4 * lg + (li >> 2)) * 16 + 4 * (li & 3);
+        int off = lane_off, step = 0, kd = 2;
+        if (slot == SLOTS - 1) {
+            kd = (mg == 0) ? 1 : 2;
+        } else {
+            const int cbl = slot / K, tap = slot - cbl * K;
+            if (cbl < g.NCB && cb0 + cbl < g.nCB) {
+                const int row0 = deint ? (tap & 1) * g.XROWS + (tap >> 1) : tap;
+                off = 512 + cbl * xsub + row0 * 16 + lane_off;
+                step = 32 * 16;
+                kd = 0;
+            }
         }
-        rowoff[mt] = off;
+        abase[mt] = off; astep[mt] = step; kind[mt] = __builtin_amdgcn_readfirstlane(kd);
     }
-    (void)nact;
-    for (int i = tid; i < ONESPe; i += 256) wlds[i] = 0x3F80;          // bf16 1.0
-    // a short last k-step reads input positions past the staged window (against zeroed dz): keep every
-    // element of the input rows finite from the start (0 * NaN would poison the accumulators)
-    for (int i = tid; i < ((nChMax * planes * XPe + 7) & ~7); i += 256) Xs[i] = 0;
+    for (int i = tid; i < 256; i += 256) reinterpret_cast<unsigned*>(wl)[i] = 0x3F803F80u;      // bf16 1.0 pairs
+    // a short last k-step reads input rows past the staged window (against zeroed dz): keep every element of the
+    // input image finite from the start (0 * NaN would poison the accumulators)
+    for (int i = tid; i < g.NCB * xsub / 2; i += 256) reinterpret_cast<unsigned*>(Xs)[i] = 0u;
 
     f32x4 acc[MTW][NW];
 #pragma unroll
@@ -100,52 +121,60 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradArgs a, int nMG
 #pragma unroll
         for (int n = 0; n < NW; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    f32x4 xreg[WUN_WGB_XIT];
+    f32x4 xra[WUN_WGB_XITP], xrb[WUN_WGB_XITP];       // channels 2*pl and 2*pl + 1 of an item
     f32x4 zreg[ZIT];
-    const int TK4 = TK >> 2;
-    const float inv_xw4 = 1.0f / (float)XW4, inv_tk4 = 1.0f / (float)TK4;
+    const int TK4 = g.TK >> 2;
+    const float inv_tk4 = 1.0f / (float)TK4;
 
-    // packed per-vector staging state (see the fp32 kernel): bit 31 live | row << 23 | c4 << 16 | LDS element offset
-    int xpk[WUN_WGB_XIT];
+    // packed per-item staging state: bit 31 live | rot << 28 | cbl << 24 | pl << 20 | c4 (position group)
+    int xpk[WUN_WGB_XITP];
     int zpk[ZIT];
+    {
+        const float inv_ncb = 1.0f / (float)g.NCB;
 #pragma unroll
-    for (int i = 0; i < WUN_WGB_XIT; ++i) {
-        const int f = tid + i * 256;
-        const int row = (int)(((float)f + 0.5f) * inv_xw4);
-        const int c4 = f - row * XW4;
-        const bool rok = row < nCh;
-        const int ldsoff = deint ? (row * 2) * XPe + 2 * c4 : row * XPe + 4 * c4;
-        xpk[i] = rok ? (int)(0x80000000u | ((unsigned)row << 23) | ((unsigned)c4 << 16) | (unsigned)ldsoff)
-                     : (int)((unsigned)c4 << 16);
+        for (int i = 0; i < WUN_WGB_XITP; ++i) {
+            const int f = tid + i * 256;
+            const int pl = f & 7, m = f >> 3;
+            const int c4 = (int)(((float)m + 0.5f) * inv_ncb);
+            const int cbl = m - c4 * g.NCB;
+            const bool live = c4 < g.XW4 && cb0 + cbl < g.nCB;
+            xpk[i] = (int)((live ? 0x80000000u : 0u) | ((unsigned)(m & 3) << 28) | ((unsigned)cbl << 24) | ((unsigned)pl << 20) |
+                           (unsigned)(c4 & 0xFFFFF));
+        }
     }
 #pragma unroll
     for (int i = 0; i < ZIT; ++i) {
         const int f = tid + i * 256;
         const int row = (int)(((float)f + 0.5f) * inv_tk4);
         const int c4 = f - row * TK4;
-        zpk[i] = row < NG ? (int)(0x80000000u | ((unsigned)row << 23) | ((unsigned)c4 << 16) | (unsigned)(row * ZPe + 4 * c4))
+        zpk[i] = row < NG ? (int)(0x80000000u | ((unsigned)row << 23) | ((unsigned)c4 << 16) | (unsigned)(row * g.ZPe + 4 * c4))
                           : (int)((unsigned)c4 << 16);
     }
 
     auto load_unit = [&](int u) {
         const int b = u / a.nQT, qt = u - b * a.nQT;
-        const int q0 = qt * TK;
+        const int q0 = qt * g.TK;
         const int tb = (deint ? 2 * q0 : q0) - a.shift;
         const float* base0 = a.src0 + (long long)b * a.bs0;
         const float* base1 = (a.C1 > 0) ? a.src1 + (long long)b * a.bs1 : base0;
         const int e00 = (tb + a.off0) & ~3, e01 = (tb + a.off1) & ~3;
 #pragma unroll
-        for (int i = 0; i < WUN_WGB_XIT; ++i) {
+        for (int i = 0; i < WUN_WGB_XITP; ++i) {
             int pk = xpk[i];
             asm volatile("" : "+v"(pk));
-            int c = cLo + ((pk >> 23) & 255);
+            int c = (cb0 + ((pk >> 24) & 15)) * 16 + 2 * ((pk >> 20) & 15);
+            int c1 = c + 1;
             c = c < Ctot ? c : Ctot - 1;
-            const bool s1 = c >= a.C0;
-            const int xro = s1 ? (c - a.C0) * a.pitch1 : c * a.pitch0;
-            int e = (s1 ? e01 : e00) + (((pk >> 16) & 127) << 2);
-            const int emax = (s1 ? a.pitch1 : a.pitch0) - 4;
+            c1 = c1 < Ctot ? c1 : Ctot - 1;
+            const bool s1 = c >= a.C0;                  // (C0 is even: both channels of a pair come from one source)
+            const int pitch = s1 ? a.pitch1 : a.pitch0;
+            const float* base = s1 ? base1 : base0;
+            const int cs = s1 ? a.C0 : 0;
+            int e = (s1 ? e01 : e00) + ((pk & 0xFFFFF) << 2);
+            const int emax = pitch - 4;
             e = e < 0 ? 0 : (e > emax ? emax : e);
-            xreg[i] = *reinterpret_cast<const f32x4*>((s1 ? base1 : base0) + xro + e);
+            xra[i] = *reinterpret_cast<const f32x4*>(base + (long long)(c - cs) * pitch + e);
+            xrb[i] = *reinterpret_cast<const f32x4*>(base + (long long)(c1 - cs) * pitch + e);
         }
         const float* zb = a.dz + (long long)b * a.dzbs;
         const int qmax = a.dzpitch - 4;
@@ -160,142 +189,315 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradArgs a, int nMG
             zreg[i] = *reinterpret_cast<const f32x4*>(zb + zro + q);
         }
     };
+    // per item: the 4 LDS destinations (element offsets from Xs; unit-invariant) in WRITE order -- write instruction k
+    // stores position (k + rot) & 3 of the item, so the 32-byte rows of 4 neighbouring position groups differ mod 4
+    // (positions before the image start, r < 0, go to a trash row behind the image)
+    const int trash = g.NCB * xsub;                       // 16 elements behind the last channel block (reserved by the launcher)
+    unsigned xdst[WUN_WGB_XITP][2];
+#pragma unroll
+    for (int i = 0; i < WUN_WGB_XITP; ++i) {
+        const int pk = xpk[i];
+        const int cbl = (pk >> 24) & 15, pl = (pk >> 20) & 15, c4 = pk & 0xFFFFF, rot = (a.ablate & 16) ? 0 : (pk >> 28) & 3;
+        const int c = (cb0 + cbl) * 16 + 2 * pl;
+        const int r0 = 4 * c4 - (c >= a.C0 ? delta1 : delta0);
+        unsigned o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + ((k + rot) & 3);
+            const int row = deint ? (r & 1) * g.XROWS + (r >> 1) : r;
+            o[k] = (unsigned)(r >= 0 ? cbl * xsub + row * 16 + 2 * pl : trash + 2 * pl);
+        }
+        xdst[i][0] = o[0] | (o[1] << 16);
+        xdst[i][1] = o[2] | (o[3] << 16);
+    }
+    const bool cedge = (cb0 + g.NCB) * 16 > Ctot;         // the last channel block of this row group is partly empty
+    const bool norot = (a.ablate & 16) != 0;
     auto store_unit = [&](int u) {
         const int b = u / a.nQT, qt = u - b * a.nQT;
-        const int q0 = qt * TK;
+        const int q0 = qt * g.TK;
         const int tb = (deint ? 2 * q0 : q0) - a.shift;
-        int nq = a.Tq - q0; if (nq > TK) nq = TK;
-        const int span = 4 * XW4;
-        const int t00 = ((tb + a.off0) & ~3) - a.off0, t01 = ((tb + a.off1) & ~3) - a.off1;
-        const bool xedge = t00 < 0 || t00 + span > a.Tin || (a.C1 > 0 && (t01 < 0 || t01 + span > a.Tin));
+        int nq = a.Tq - q0; if (nq > g.TK) nq = g.TK;
+        // interior units (every staged position inside the input, full channel blocks) skip the per-element tests
+        const bool edge = cedge || tb - 3 < 0 || tb + 4 * g.XW4 > a.Tin;
 #pragma unroll
-        for (int i = 0; i < WUN_WGB_XIT; ++i) {
+        for (int i = 0; i < WUN_WGB_XITP; ++i) {
             int pk = xpk[i];
             asm volatile("" : "+v"(pk));
             if (pk < 0) {
-                f32x4 v = xreg[i];
-                if (xedge) {
-                    const bool s1 = cLo + ((pk >> 23) & 255) >= a.C0;
-                    const int t0 = (s1 ? t01 : t00) + (((pk >> 16) & 127) << 2);
+                f32x4 ua = xra[i], ub = xrb[i];
+                if (edge) {
+                    const int cbl = (pk >> 24) & 15, pl = (pk >> 20) & 15, c4 = pk & 0xFFFFF;
+                    const int c = (cb0 + cbl) * 16 + 2 * pl;
+                    const int t0 = tb + 4 * c4 - (c >= a.C0 ? delta1 : delta0);    // position in the source's own time axis
+                    const bool va = c < Ctot, vb = c + 1 < Ctot;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (t0 + k < 0 || t0 + k >= a.Tin) v[k] = 0.f;
+                    for (int k = 0; k < 4; ++k) {
+                        const bool in = t0 + k >= 0 && t0 + k < a.Tin;
+                        ua[k] = in && va ? ua[k] : 0.f;
+                        ub[k] = in && vb ? ub[k] : 0.f;
+                    }
                 }
-                unsigned short* dstp = Xs + (pk & 0xFFFF);
-                if (!deint) {
-                    *reinterpret_cast<u32x2*>(dstp) = (u32x2){wb_pack2(v[0], v[1]), wb_pack2(v[2], v[3])};
-                } else {
-                    *reinterpret_cast<unsigned*>(dstp) = wb_pack2(v[0], v[2]);
-                    *reinterpret_cast<unsigned*>(dstp + XPe) = wb_pack2(v[1], v[3]);
-                }
+                unsigned d[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[k] = wb_pack2(ua[k], ub[k]);
+                const int rot = norot ? 0 : (pk >> 28) & 3;
+                if (rot & 1) { const unsigned t = d[0]; d[0] = d[1]; d[1] = d[2]; d[2] = d[3]; d[3] = t; }
+                if (rot & 2) { unsigned t = d[0]; d[0] = d[2]; d[2] = t; t = d[1]; d[1] = d[3]; d[3] = t; }
+                unsigned w0 = xdst[i][0], w1 = xdst[i][1];
+                asm volatile("" : "+v"(w0), "+v"(w1));
+                *reinterpret_cast<unsigned*>(Xs + (w0 & 0xFFFF)) = d[0];
+                *reinterpret_cast<unsigned*>(Xs + (w0 >> 16)) = d[1];
+                *reinterpret_cast<unsigned*>(Xs + (w1 & 0xFFFF)) = d[2];
+                *reinterpret_cast<unsigned*>(Xs + (w1 >> 16)) = d[3];
             }
         }
         // positions beyond nq are zero in dz, so whatever the input rows hold there contributes nothing
+        const bool zedge = nq < g.TK;
 #pragma unroll
         for (int i = 0; i < ZIT; ++i) {
             int pk = zpk[i];
             asm volatile("" : "+v"(pk));
             if (pk < 0) {
                 f32x4 v = zreg[i];
-                const int c4x = ((pk >> 16) & 127) << 2;
+                if (zedge) {
+                    const int c4x = ((pk >> 16) & 127) << 2;
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (c4x + k >= nq) v[k] = 0.f;
+                    for (int k = 0; k < 4; ++k)
+                        if (c4x + k >= nq) v[k] = 0.f;
+                }
                 *reinterpret_cast<u32x2*>(Zs + (pk & 0xFFFF)) = (u32x2){wb_pack2(v[0], v[1]), wb_pack2(v[2], v[3])};
             }
         }
         (void)b;
     };
 
+    // diagnostic switches (WUN_WGB_ABL; uniform branches): 1 no global loads, 2 no LDS stores, 4 no MFMA loop, 8 no barriers
+    const bool ab_noload = a.ablate & 1, ab_nostore = a.ablate & 2, ab_nomfma = a.ablate & 4, ab_nobar = a.ablate & 8;
     const int nunits = a.B * a.nQT;
     const int u0 = split * a.units_per_split;
     int u1 = u0 + a.units_per_split;
     if (u1 > nunits) u1 = nunits;
-    // the dz tile of a short last unit is only written up to TK: clear the tail k-step once if TK is not a multiple of 32
-    const int TKr = (TK + 31) & ~31;
-    if (TKr != TK)
-        for (int i = tid; i < NG * (TKr - TK); i += 256) Zs[(i / (TKr - TK)) * ZPe + TK + i % (TKr - TK)] = 0;
-    if (u0 < u1) load_unit(u0);
+    // the dz tile of a unit is only written up to TK: clear the tail of the last k-step once if TK is not a multiple of 32
+    const int TKr = (g.TK + 31) & ~31;
+    if (TKr != g.TK)
+        for (int i = tid; i < NG * (TKr - g.TK); i += 256) Zs[(i / (TKr - g.TK)) * g.ZPe + g.TK + i % (TKr - g.TK)] = 0;
+    // experiment: co-resident workgroups (hardware ids 256 apart) start out of phase by (a.ablate >> 8) * 64 clocks each
+    if (a.ablate >> 8) {
+        const int lag = ((int)blockIdx.x >> 8) % 3;
+        for (int r = 0; r < lag * (a.ablate >> 8); ++r) __builtin_amdgcn_s_sleep(1);
+    }
+    if (ab_noload) {
+#pragma unroll
+        for (int i = 0; i < WUN_WGB_XITP; ++i) { xra[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; xrb[i] = xra[i]; }
+#pragma unroll
+        for (int i = 0; i < ZIT; ++i) zreg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if (u0 < u1 && !ab_noload) load_unit(u0);
     for (int u = u0; u < u1; ++u) {
-        __syncthreads();
-        store_unit(u);
-        __syncthreads();
-        if (u + 1 < u1) load_unit(u + 1);
+        if (!ab_nobar) __syncthreads();
+        if (!ab_nostore) store_unit(u);
+        if (!ab_nobar) __syncthreads();
+        if (u + 1 < u1 && !ab_noload) load_unit(u + 1);
         const int qt = u % a.nQT;
-        int nq = a.Tq - qt * TK; if (nq > TK) nq = TK;
-        const int nsteps = (nq + 31) >> 5;                 // k-steps of 32 positions
+        int nq = a.Tq - qt * g.TK; if (nq > g.TK) nq = g.TK;
+        const int nsteps = ab_nomfma ? 0 : (nq + 31) >> 5; // k-steps of 32 positions
         for (int st = 0; st < nsteps; ++st) {
-            bf16x8 av[MTW], bv[NW];
+            bf16x8 bv[NW];
+#pragma unroll
+            for (int n = 0; n < NW; ++n) {
+                const unsigned short* zp = Zs + (n * 16 + li) * g.ZPe + st * 32 + 4 * lg;
+                const u32x2 lo = *reinterpret_cast<const u32x2*>(zp);
+                const u32x2 hi = *reinterpret_cast<const u32x2*>(zp + 16);
+                bv[n] = __builtin_bit_cast(bf16x8, (u32x4){lo[0], lo[1], hi[0], hi[1]});
+            }
+            bf16x8 av[MTW];
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt) {
-                const unsigned short* xp = wlds + rowoff[mt] + st * 32 + 8 * lg;
-                u32x4 w = {(unsigned)xp[0] | ((unsigned)xp[1] << 16), (unsigned)xp[2] | ((unsigned)xp[3] << 16),
-                           (unsigned)xp[4] | ((unsigned)xp[5] << 16), (unsigned)xp[6] | ((unsigned)xp[7] << 16)};
-                av[mt] = __builtin_bit_cast(bf16x8, w);
+                const unsigned short* xp = wl + abase[mt];
+                const u32x2 lo = wb_tr_read(xp);
+                const u32x2 hi = wb_tr_read(xp + 16 * 16);
+                av[mt] = __builtin_bit_cast(bf16x8, (u32x4){lo[0], lo[1], hi[0], hi[1]});
+                abase[mt] += astep[mt];
             }
-#pragma unroll
-            for (int n = 0; n < NW; ++n)
-                bv[n] = *reinterpret_cast<const bf16x8*>(Zs + (n * 16 + li) * ZPe + st * 32 + 8 * lg);
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
                 for (int n = 0; n < NW; ++n)
                     acc[mt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[mt], bv[n], acc[mt][n], 0, 0, 0);
         }
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) abase[mt] -= nsteps * astep[mt];
     }
 
     if (!a.direct) {
         f32x4* tile = reinterpret_cast<f32x4*>(a.out) +
-                      ((((long long)(a.split_base + split) * nMG + mg) * nNG + ng) * (MG * NG / 4)) +
+                      ((((long long)(a.split_base + split) * g.nMG + mg) * g.nNG + ng) * (SLOTS * 16 * NG / 4)) +
                       wave * (MTW * NW * 64) + lane;
 #pragma unroll
-        for (int mt = 0; mt < MTW; ++mt)
+        for (int mt = 0; mt < MTW; ++mt) {
+            if (kind[mt] == 2) continue;                   // idle: never read by the reduction
 #pragma unroll
             for (int n = 0; n < NW; ++n) tile[(mt * NW + n) * 64] = acc[mt][n];
+        }
         return;
     }
-    float* outp = a.out;
+    float* outp = a.out;                                   // single split: final layout [K][Cin][Cout] + bias row
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
+        const int slot = wave * MTW + mt;
+        if (kind[mt] == 2) continue;
 #pragma unroll
         for (int n = 0; n < NW; ++n) {
             const int col = ng * NG + n * 16 + li;
             if (col >= a.N) continue;
+            if (kind[mt] == 1) {
+                if (lg == 0) outp[(long long)K * Ctot * a.N + col] = acc[mt][n][0];
+                continue;
+            }
+            const int cbl = slot / K, tap = slot - cbl * K;
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-                const int r = rlo + (wave * MTW + mt) * 16 + lg * 4 + r4;
-                if (r < Mtot) {
-                    const int c = r / a.KW, k = r - c * a.KW;
-                    outp[((long long)k * Ctot + c) * a.N + col] = acc[mt][n][r4];
-                } else if (r == Mtot) {
-                    outp[(long long)Mtot * a.N + col] = acc[mt][n][r4];
-                }
+                const int c = (cb0 + cbl) * 16 + lg * 4 + r4;
+                if (c < Ctot) outp[((long long)tap * Ctot + c) * a.N + col] = acc[mt][n][r4];
             }
         }
     }
 }
 
+// Sums the tile-major split partials in split order (SL split lanes per element, combined in lane order:
+// deterministic) and scatters to out_w[K][Cin][Cout], out_b[Cout].  One thread = one f32x4 accumulator register.
+struct WgradBfReduceArgs {
+    const float* partial; float* out_w; float* out_b;
+    int nsplit, MTW, NW, NCB, nCB, nMG, nNG, KW, Ctot, N;
+};
+
+template <int SL>
+__global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(WgradBfReduceArgs a) {
+    __shared__ f32x4 red[SL > 1 ? 256 : 1];
+    constexpr int VPB = 256 / SL;                                  // vector slots per block
+    const int SLOTS = 4 * a.MTW, NG = a.NW * 16;
+    const int tile_v = SLOTS * 16 * NG / 4;                        // f32x4 slots per (row group, column group) tile
+    const int slot_v = threadIdx.x % VPB, sl = threadIdx.x / VPB;
+    const long long gv = (long long)blockIdx.x * VPB + slot_v;     // global slot over all tiles
+    const long long ntile = (long long)a.nMG * a.nNG;
+    bool live = gv < ntile * tile_v;
+    // decode first: idle slots were never written
+    int mg = 0, col = 0, slot = 0, lg = 0;
+    if (live) {
+        const int t = (int)(gv / tile_v), v = (int)(gv % tile_v);
+        mg = t / a.nNG;
+        const int ng = t % a.nNG;
+        const int per_wave = a.MTW * a.NW * 64;
+        const int wave = v / per_wave, rem = v % per_wave;
+        const int tn = rem / 64, lane = rem % 64;
+        const int mt = tn / a.NW, n = tn % a.NW;
+        lg = lane >> 4;
+        col = ng * NG + n * 16 + (lane & 15);
+        slot = wave * a.MTW + mt;
+        if (slot == SLOTS - 1) live = mg == 0;
+        else { const int cbl = slot / a.KW; live = cbl < a.NCB && mg * a.NCB + cbl < a.nCB; }
+    }
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(a.partial) + gv;
+        const long long sstride = ntile * tile_v;
+        int k = sl;
+        for (; k + 7 * SL < a.nsplit; k += 8 * SL) {               // batches of independent loads, summed in split order
+            f32x4 t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = p[(long long)(k + j * SL) * sstride];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += t[j];
+        }
+        for (; k < a.nsplit; k += SL) sum += p[(long long)k * sstride];
+    }
+    if constexpr (SL > 1) {
+        red[threadIdx.x] = sum;
+        __syncthreads();
+        if (sl != 0) return;
+        sum = red[slot_v];
+#pragma unroll
+        for (int k = 1; k < SL; ++k) sum += red[k * VPB + slot_v];
+    }
+    if (!live || col >= a.N) return;
+    if (slot == SLOTS - 1) {
+        if (lg == 0) a.out_b[col] = sum[0];
+        return;
+    }
+    const int cbl = slot / a.KW, tap = slot - cbl * a.KW;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        const int c = (mg * a.NCB + cbl) * 16 + lg * 4 + r4;
+        if (c < a.Ctot) a.out_w[((long long)tap * a.Ctot + c) * a.N + col] = sum[r4];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side: geometry, launchers
+// ---------------------------------------------------------------------------------------
+bool wgrad_bf16_supported(const WgradArgs& a) {
+    if (a.KW < 1 || a.KW > 15 || a.C0 + a.C1 < 8) return false;
+    if (a.C1 > 0 && (a.C0 & 1)) return false;          // a staged channel pair must not straddle the two sources
+    return true;
+}
+
+WgradBfGeom wgrad_bf16_geom(const WgradArgs& a) {
+    WgradBfGeom g;
+    const int Ctot = a.C0 + a.C1, K = a.KW;
+    const bool deint = a.loader == LOADER_DEINT;
+    g.nCB = (Ctot + 15) / 16;
+    // columns: the tile count (2..4) that pads the output channels least, wider on ties
+    int bestnw = 4, bestpad = 1 << 30;
+    for (int nw = 4; nw >= 2; --nw) {
+        const int padded = ((a.N + nw * 16 - 1) / (nw * 16)) * nw * 16;
+        if (padded < bestpad) { bestpad = padded; bestnw = nw; }
+    }
+    if (a.N <= 16) bestnw = 1;
+    g.NW = (a.force_nw >= 1 && a.force_nw <= 4) ? a.force_nw : bestnw;
+    // rows: 4 tiles per wave; 8 (half as many row groups, each of which re-reads the dz tile, but 2 instead of 3
+    // resident workgroups per CU) only when the autotuner measured it faster
+    const int ncb4 = std::max(1, std::min(g.nCB, 15 / K)), ncb8 = std::max(1, std::min(g.nCB, 31 / K));
+    int mtw = 4;
+    if (a.force_mtw == 4 || a.force_mtw == 8) mtw = a.force_mtw;
+    if (mtw == 8 && g.NW > 3) mtw = 4;                  // accumulator budget
+    g.MTW = mtw;
+    g.NCB = mtw == 8 ? ncb8 : ncb4;
+    g.nMG = (g.nCB + g.NCB - 1) / g.NCB;
+    g.nNG = (a.N + g.NW * 16 - 1) / (g.NW * 16);
+    int tk = (a.Tq + 3) & ~3;
+    if (tk > 128) tk = 128;
+    if (tk < 4) tk = 4;
+    for (;;) {
+        const int need = deint ? 2 * tk + K - 1 : tk + K - 1;         // staged positions of a unit (+ 3 of alignment slack)
+        g.XW4 = (need + 3 + 3) / 4;
+        if ((long long)8 * g.NCB * g.XW4 <= (long long)WUN_WGB_XITP * 256 || tk <= 32) break;
+        tk = (tk / 2 + 3) & ~3;
+    }
+    while ((long long)8 * g.NCB * g.XW4 > (long long)WUN_WGB_XITP * 256 && g.NCB > 1) --g.NCB;    // (1-tap filters)
+    g.nMG = (g.nCB + g.NCB - 1) / g.NCB;
+    g.TK = tk;
+    const int tkr = (tk + 31) & ~31;
+    const int rows = deint ? std::max(tkr + (K + 1) / 2, 2 * g.XW4 + 1) : std::max(tkr + K - 1, 4 * g.XW4);
+    g.XROWS = (rows + 3) & ~3;
+    g.ZPe = tkr + 8;
+    g.lds = 2 * (512 + (size_t)g.NCB * (deint ? 2 : 1) * g.XROWS * 16 + 64 + (size_t)g.NW * 16 * g.ZPe);
+    return g;
+}
+
 template <int MTW, int NW>
-static hipError_t wgrad_bf16_launch_t(WgradArgs a, const WgradGeom& g, hipStream_t s) {
+static hipError_t wgrad_bf16_launch_t(WgradArgs a, const WgradBfGeom& g, hipStream_t s) {
     a.nQT = (a.Tq + g.TK - 1) / g.TK;
     const long long units = (long long)a.B * a.nQT;
     a.units_per_split = (int)((units + a.nsplit - 1) / a.nsplit);
-    const bool deint = a.loader == LOADER_DEINT;
-    const int TKr = (g.TK + 31) & ~31;
-    // element pitches: input rows hold 4*XW4 (stride 1) or 2*XW4 per plane (stride 2) staged positions, plus the read
-    // overhang of the last k-step (tap + shift + up to 31 positions of a short unit); dz rows 2*TKr + 32 bytes
-    const int xneed = (deint ? 2 * g.XW4 : 4 * g.XW4) + 32 + 24;
-    const int XPe = (xneed + 3) / 4 * 4 + 4;
-    const int ZPe = TKr + 16;
-    const int ONESPe = TKr + 32;
-    const size_t lds = 2 * ((size_t)ONESPe + (((size_t)g.nChMax * (deint ? 2 : 1) * XPe + 7) & ~(size_t)7) + (size_t)(NW * 16) * ZPe);
-    if (lds > 160 * 1024 || (size_t)g.nChMax * (deint ? 2 : 1) * XPe > 65535 || (size_t)(NW * 16) * ZPe > 65535) return hipErrorInvalidValue;
+    if (g.lds > 160 * 1024 || (size_t)(NW * 16) * g.ZPe > 65535 || g.XW4 >= (1 << 20)) return hipErrorInvalidValue;
+    if ((size_t)g.NCB * (a.loader == LOADER_DEINT ? 2 : 1) * g.XROWS * 16 + 80 > 65535) return hipErrorInvalidValue;   // 16-bit LDS destinations
+    if ((long long)8 * g.NCB * g.XW4 > (long long)WUN_WGB_XITP * 256) return hipErrorInvalidValue;
     auto kern = wgrad_bf16_kernel<MTW, NW>;
     static size_t lds_allowed = 64 * 1024;
-    if (lds > lds_allowed) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (g.lds > lds_allowed) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
         if (e != hipSuccess) return e;
-        lds_allowed = lds;
+        lds_allowed = g.lds;
     }
     const long long grid = (long long)g.nMG * g.nNG * a.nsplit;
     char nm[64], tag[160];
@@ -303,26 +505,42 @@ static hipError_t wgrad_bf16_launch_t(WgradArgs a, const WgradGeom& g, hipStream
     snprintf(tag, sizeof(tag), "C=%d N=%d T=%d K=%d ld=%d B=%d nsplit=%d grid=%lld", a.C0 + a.C1, a.N, a.Tq, a.KW, a.loader, a.B,
              a.nsplit, grid);
     prof_scope_begin(nm, 2.0 * a.KW * (double)(a.C0 + a.C1) * a.N * (double)a.Tq * a.B, s, tag);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a, g.nMG, g.nNG, g.TK, XPe, ZPe, g.nChMax, ONESPe, g.XW4);
+    WgBfK k;
+    k.NCB = g.NCB; k.nCB = g.nCB; k.nMG = g.nMG; k.nNG = g.nNG; k.TK = g.TK; k.XW4 = g.XW4; k.XROWS = g.XROWS; k.ZPe = g.ZPe;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), g.lds, s, a, k);
     prof_scope_end(s);
     return hipGetLastError();
 }
 
 hipError_t launch_wgrad_bf16(const WgradArgs& a, hipStream_t s) {
+    if (!wgrad_bf16_supported(a)) return hipErrorInvalidValue;
+    if (const char* e = getenv("WUN_WGB_ABL")) const_cast<WgradArgs&>(a).ablate = atoi(e);
     if ((a.pitch0 & 3) || (a.bs0 & 3) || (reinterpret_cast<uintptr_t>(a.src0) & 15) || a.pitch0 < 4) return hipErrorInvalidValue;
     if (a.C1 > 0 && ((a.pitch1 & 3) || (a.bs1 & 3) || (reinterpret_cast<uintptr_t>(a.src1) & 15) || a.pitch1 < 4)) return hipErrorInvalidValue;
     if ((a.dzpitch & 3) || (a.dzbs & 3) || (reinterpret_cast<uintptr_t>(a.dz) & 15) || a.dzpitch < 4) return hipErrorInvalidValue;
-    const WgradGeom g = wgrad_geom(a);
-    if ((long long)g.nChMax * g.XW4 > (long long)WUN_WGB_XIT * 256) return hipErrorInvalidValue;
+    const WgradBfGeom g = wgrad_bf16_geom(a);
 #define WUN_WGB(M, N) if (g.MTW == M && g.NW == N) return wgrad_bf16_launch_t<M, N>(a, g, s);
-    WUN_WGB(1, 1) WUN_WGB(1, 2) WUN_WGB(1, 3)
-    WUN_WGB(2, 1) WUN_WGB(2, 2) WUN_WGB(2, 3)
-    WUN_WGB(4, 1) WUN_WGB(4, 2) WUN_WGB(4, 3)
-    WUN_WGB(6, 1) WUN_WGB(6, 2) WUN_WGB(6, 3)
-    WUN_WGB(1, 4) WUN_WGB(2, 4) WUN_WGB(4, 4)
-    WUN_WGB(1, 5) WUN_WGB(2, 5) WUN_WGB(4, 5)
+    WUN_WGB(4, 1) WUN_WGB(4, 2) WUN_WGB(4, 3) WUN_WGB(4, 4)
+    WUN_WGB(8, 1) WUN_WGB(8, 2) WUN_WGB(8, 3)
 #undef WUN_WGB
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_wgrad_bf16_reduce(const WgradArgs& a, const float* partial, int nsplit, float* out_w, float* out_b,
+                                    hipStream_t s) {
+    const WgradBfGeom g = wgrad_bf16_geom(a);
+    WgradBfReduceArgs r;
+    r.partial = partial; r.out_w = out_w; r.out_b = out_b;
+    r.nsplit = nsplit; r.MTW = g.MTW; r.NW = g.NW; r.NCB = g.NCB; r.nCB = g.nCB; r.nMG = g.nMG; r.nNG = g.nNG;
+    r.Ctot = a.C0 + a.C1; r.KW = a.KW; r.N = a.N;
+    const long long slots = (long long)g.nMG * g.nNG * (4 * g.MTW * 16) * (g.NW * 16) / 4;
+    const int sl = (nsplit >= 64 && slots < (1 << 16)) ? 16 : (nsplit >= 8 && slots < (1 << 18) ? 4 : 1);
+    const int vpb = 256 / sl;
+    const long long blocks = (slots + vpb - 1) / vpb;
+    if (sl == 16) hipLaunchKernelGGL(wgrad_bf16_reduce_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, r);
+    else if (sl == 4) hipLaunchKernelGGL(wgrad_bf16_reduce_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, r);
+    else hipLaunchKernelGGL(wgrad_bf16_reduce_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, r);
+    return hipGetLastError();
 }
 
 }  // namespace wun
