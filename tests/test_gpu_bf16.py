@@ -165,8 +165,8 @@ BF16_WGRAD_CASES = [
     (2, 104, 40, 3, 333, 1, 1, True),            # 5 channel blocks per workgroup (3 taps)
     (2, 32, 24, 15, 131, 2, 0, False),
 ]
-# (tiles per wave, column tiles) of the bf16 kernel: 4 x {1..4}, 8 x {1..3}; (0, 0) = heuristic
-WGRAD_GEOMS = [(0, 0)] + [(4, n) for n in (1, 2, 3, 4)] + [(8, n) for n in (1, 2, 3)]
+# (tiles per wave, column tiles) of the bf16 kernel: 4 x {1..5}, 8 x {1..3}; (0, 0) = heuristic
+WGRAD_GEOMS = [(0, 0)] + [(4, n) for n in (1, 2, 3, 4, 5)] + [(8, n) for n in (1, 2, 3)]
 
 
 @pytest.mark.parametrize("case", BF16_WGRAD_CASES, ids=[str(c) for c in BF16_WGRAD_CASES])

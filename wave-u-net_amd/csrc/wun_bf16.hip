@@ -382,10 +382,11 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
     //   S > 1 : tpw == 1, the inner stage loop double-buffers weights + input window;
     //   S == 1: weights stay, the tile loop double-buffers the input window of the next tile.
     int b, q0;
+    // diagnostic switches (WUN_BF_ABL, uniform): 1 no MFMA, 2 no epilogue, 4 no input staging, 8 no weight DMA
+    const bool ab_nomfma = a.flags & 0x10000, ab_noepi = a.flags & 0x20000, ab_nox = a.flags & 0x40000, ab_now = a.flags & 0x80000;
     set_tile(tix0, b, q0);
-    dma_w(0, 0);
-    load_x(0);
-    store_x(0, 0);
+    if (!ab_now) dma_w(0, 0);
+    if (!ab_nox) { load_x(0); store_x(0, 0); }
     __syncthreads();
     if constexpr (!WS) {
         // ---- one output tile: weights and input window of stage st+1 stream in under the MFMAs of stage st ----
@@ -393,16 +394,16 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
         for (int st = 0; st < S; ++st) {
             const bool has_next = st + 1 < S;
             if (has_next) {
-                dma_w(st + 1, (st + 1) & 1);
-                load_x(st + 1);
+                if (!ab_now) dma_w(st + 1, (st + 1) & 1);
+                if (!ab_nox) load_x(st + 1);
             }
-            run_stage(st & 1, st & 1);
+            if (!ab_nomfma) run_stage(st & 1, st & 1);
             if (has_next) {
-                store_x(st + 1, (st + 1) & 1);
+                if (!ab_nox) store_x(st + 1, (st + 1) & 1);
                 __syncthreads();
             }
         }
-        epilogue(b, q0);
+        if (!ab_noepi) epilogue(b, q0);
     } else {
         // ---- weights-stationary (S == 1): walk this workgroup's time tiles, input window double-buffered ----
         int xb = 0;
@@ -412,10 +413,10 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
             zero_acc();
             if (next_tile) {
                 set_tile(tix + 1, b, q0);
-                if (!(a.flags & 0x40000)) load_x(0);
+                if (!ab_nox) load_x(0);
             }
-            if (!(a.flags & 0x10000)) run_stage(xb, 0);
-            if (!(a.flags & 0x20000)) epilogue(bc, qc);
+            if (!ab_nomfma) run_stage(xb, 0);
+            if (!ab_noepi) epilogue(bc, qc);
             if (next_tile) {
                 store_x(0, xb ^ 1);
                 __syncthreads();

@@ -446,14 +446,14 @@ WgradBfGeom wgrad_bf16_geom(const WgradArgs& a) {
     const int Ctot = a.C0 + a.C1, K = a.KW;
     const bool deint = a.loader == LOADER_DEINT;
     g.nCB = (Ctot + 15) / 16;
-    // columns: the tile count (2..4) that pads the output channels least, wider on ties
+    // columns: the tile count (2..5) that pads the output channels least, wider on ties
     int bestnw = 4, bestpad = 1 << 30;
-    for (int nw = 4; nw >= 2; --nw) {
+    for (int nw = 5; nw >= 2; --nw) {
         const int padded = ((a.N + nw * 16 - 1) / (nw * 16)) * nw * 16;
         if (padded < bestpad) { bestpad = padded; bestnw = nw; }
     }
     if (a.N <= 16) bestnw = 1;
-    g.NW = (a.force_nw >= 1 && a.force_nw <= 4) ? a.force_nw : bestnw;
+    g.NW = (a.force_nw >= 1 && a.force_nw <= 5) ? a.force_nw : bestnw;
     // rows: 4 tiles per wave; 8 (half as many row groups, each of which re-reads the dz tile, but 2 instead of 3
     // resident workgroups per CU) only when the autotuner measured it faster
     const int ncb4 = std::max(1, std::min(g.nCB, 15 / K)), ncb8 = std::max(1, std::min(g.nCB, 31 / K));
@@ -520,7 +520,7 @@ hipError_t launch_wgrad_bf16(const WgradArgs& a, hipStream_t s) {
     if ((a.dzpitch & 3) || (a.dzbs & 3) || (reinterpret_cast<uintptr_t>(a.dz) & 15) || a.dzpitch < 4) return hipErrorInvalidValue;
     const WgradBfGeom g = wgrad_bf16_geom(a);
 #define WUN_WGB(M, N) if (g.MTW == M && g.NW == N) return wgrad_bf16_launch_t<M, N>(a, g, s);
-    WUN_WGB(4, 1) WUN_WGB(4, 2) WUN_WGB(4, 3) WUN_WGB(4, 4)
+    WUN_WGB(4, 1) WUN_WGB(4, 2) WUN_WGB(4, 3) WUN_WGB(4, 4) WUN_WGB(4, 5)
     WUN_WGB(8, 1) WUN_WGB(8, 2) WUN_WGB(8, 3)
 #undef WUN_WGB
     return hipErrorInvalidValue;
