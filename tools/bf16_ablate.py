@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic (GPU box): time the bf16 conv operator on one layer shape with phases of the kernel switched off
-(WUN_BF_ABL bits: 1 no MFMA, 2 no epilogue, 4 no input loads, 8 no weight DMA).
+(WUN_BF_ABL bits: 1 no MFMA, 2 no epilogue, 4 no input loads, 8 no weight DMA; needs a library built with
+make -C wave-u-net_amd/csrc EXTRA=-DWUN_BF_ABLATION).
 usage: python tools/bf16_ablate.py B Cin Cout K T stride"""
 import ctypes as C
 import os

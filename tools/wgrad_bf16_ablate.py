@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic (GPU box): time the bf16 weight-gradient operator on one layer shape with phases of the kernel switched
-off (WUN_WGB_ABL bits: 1 no global loads, 2 no LDS stores, 4 no MFMA loop, 8 no barriers).
+off (WUN_WGB_ABL bits: 1 no global loads, 2 no LDS stores, 4 no MFMA loop, 8 no barriers, 16 no write rotation;
+needs a library built with make -C wave-u-net_amd/csrc EXTRA=-DWUN_BF_ABLATION).
 usage: python tools/wgrad_bf16_ablate.py B Cin Cout K T stride [mtw nw nsplit]"""
 import ctypes as C
 import json

@@ -382,8 +382,13 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
     //   S > 1 : tpw == 1, the inner stage loop double-buffers weights + input window;
     //   S == 1: weights stay, the tile loop double-buffers the input window of the next tile.
     int b, q0;
-    // diagnostic switches (WUN_BF_ABL, uniform): 1 no MFMA, 2 no epilogue, 4 no input staging, 8 no weight DMA
+    // diagnostic switches (WUN_BF_ABL, uniform; only in builds with -DWUN_BF_ABLATION -- the extra branches cost the
+    // narrow layers 4 %): 1 no MFMA, 2 no epilogue, 4 no input staging, 8 no weight DMA
+#ifdef WUN_BF_ABLATION
     const bool ab_nomfma = a.flags & 0x10000, ab_noepi = a.flags & 0x20000, ab_nox = a.flags & 0x40000, ab_now = a.flags & 0x80000;
+#else
+    constexpr bool ab_nomfma = false, ab_noepi = false, ab_nox = false, ab_now = false;
+#endif
     set_tile(tix0, b, q0);
     if (!ab_now) dma_w(0, 0);
     if (!ab_nox) { load_x(0); store_x(0, 0); }

@@ -192,12 +192,17 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a, WgBfK g) {
     // per item: the 4 LDS destinations (element offsets from Xs; unit-invariant) in WRITE order -- write instruction k
     // stores position (k + rot) & 3 of the item, so the 32-byte rows of 4 neighbouring position groups differ mod 4
     // (positions before the image start, r < 0, go to a trash row behind the image)
+#ifdef WUN_BF_ABLATION
+    const bool norot = (a.ablate & 16) != 0;
+#else
+    constexpr bool norot = false;
+#endif
     const int trash = g.NCB * xsub;                       // 16 elements behind the last channel block (reserved by the launcher)
     unsigned xdst[WUN_WGB_XITP][2];
 #pragma unroll
     for (int i = 0; i < WUN_WGB_XITP; ++i) {
         const int pk = xpk[i];
-        const int cbl = (pk >> 24) & 15, pl = (pk >> 20) & 15, c4 = pk & 0xFFFFF, rot = (a.ablate & 16) ? 0 : (pk >> 28) & 3;
+        const int cbl = (pk >> 24) & 15, pl = (pk >> 20) & 15, c4 = pk & 0xFFFFF, rot = norot ? 0 : (pk >> 28) & 3;
         const int c = (cb0 + cbl) * 16 + 2 * pl;
         const int r0 = 4 * c4 - (c >= a.C0 ? delta1 : delta0);
         unsigned o[4];
@@ -211,7 +216,6 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a, WgBfK g) {
         xdst[i][1] = o[2] | (o[3] << 16);
     }
     const bool cedge = (cb0 + g.NCB) * 16 > Ctot;         // the last channel block of this row group is partly empty
-    const bool norot = (a.ablate & 16) != 0;
     auto store_unit = [&](int u) {
         const int b = u / a.nQT, qt = u - b * a.nQT;
         const int q0 = qt * g.TK;
@@ -271,8 +275,13 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a, WgBfK g) {
         (void)b;
     };
 
-    // diagnostic switches (WUN_WGB_ABL; uniform branches): 1 no global loads, 2 no LDS stores, 4 no MFMA loop, 8 no barriers
+    // diagnostic switches (WUN_WGB_ABL; uniform branches; builds with -DWUN_BF_ABLATION only): 1 no global loads,
+    // 2 no LDS stores, 4 no MFMA loop, 8 no barriers, 16 no write rotation
+#ifdef WUN_BF_ABLATION
     const bool ab_noload = a.ablate & 1, ab_nostore = a.ablate & 2, ab_nomfma = a.ablate & 4, ab_nobar = a.ablate & 8;
+#else
+    constexpr bool ab_noload = false, ab_nostore = false, ab_nomfma = false, ab_nobar = false;
+#endif
     const int nunits = a.B * a.nQT;
     const int u0 = split * a.units_per_split;
     int u1 = u0 + a.units_per_split;
@@ -281,11 +290,6 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a, WgBfK g) {
     const int TKr = (g.TK + 31) & ~31;
     if (TKr != g.TK)
         for (int i = tid; i < NG * (TKr - g.TK); i += 256) Zs[(i / (TKr - g.TK)) * g.ZPe + g.TK + i % (TKr - g.TK)] = 0;
-    // experiment: co-resident workgroups (hardware ids 256 apart) start out of phase by (a.ablate >> 8) * 64 clocks each
-    if (a.ablate >> 8) {
-        const int lag = ((int)blockIdx.x >> 8) % 3;
-        for (int r = 0; r < lag * (a.ablate >> 8); ++r) __builtin_amdgcn_s_sleep(1);
-    }
     if (ab_noload) {
 #pragma unroll
         for (int i = 0; i < WUN_WGB_XITP; ++i) { xra[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; xrb[i] = xra[i]; }
