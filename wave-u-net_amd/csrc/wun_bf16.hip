@@ -64,7 +64,10 @@ template <int MT> struct BfXit { static constexpr int v = MT == 4 ? 9 : (MT == 2
 //     all of the HBM traffic): WEIGHTS-STATIONARY.  A workgroup loads its column tile's weights once and
 //     walks `tpw` consecutive time tiles; the input window of tile i+1 streams in (double-buffered) while
 //     tile i computes and stores, so a tile costs its MFMAs, not a dependent chain of memory round trips.
-template <int MT, int NW, bool WS>
+// MODE: 0 stride-1 loader, 1 stride-2 (even / odd planes) loader, 2 fused two-phase transposed conv (stride-1 loader).
+// Compile-time, like the schedule: at bf16 MFMA rates the narrow layers are bound by the instruction stream around the
+// MFMAs, and four uniform run-time branches in the stage loop were measured to cost them 4 %.
+template <int MT, int NW, bool WS, int MODE>
 __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int nNT, int NCK, int ROWS, int tpw_arg) {
     const int tpw = WS ? tpw_arg : 1;                       // WS: weights-stationary walk over tpw time tiles (own instantiation:
                                                             // the one-tile kernel must not pay its registers)
@@ -73,8 +76,8 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
     constexpr int TT = WT * MT * 16;
     constexpr int NT = NW * 16;
     constexpr int XIT = BfXit<MT>::v;
-    const bool deint = (a.loader == LOADER_DEINT);
-    const int planes = deint ? 2 : 1;
+    constexpr bool deint = MODE == 1;
+    constexpr int planes = deint ? 2 : 1;
     const int KW = a.KW;
     const int XPB = 64 * NCK + 32;                          // bytes per X row: conflict-free for ds_read_b128 at every tap
     const int C8S = 4 * NCK;                                // 8-channel groups per stage
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
     // fused two-phase transposed stride-2 conv (F_PHASE2): the weight matrix has 2*N columns (phase 0 | phase 1 of the N
     // output channels); a workgroup takes NT/2 channels x both phases -- column tiles [0, NW/2) are phase 0 (outputs
     // t = 2q), tiles [NW/2, NW) phase 1 (t = 2q + 1) of the SAME channels, so a lane owns 8 consecutive output samples
-    const bool phase2 = (a.flags & F_PHASE2) != 0;
+    constexpr bool phase2 = MODE == 2;
     const int n0 = phase2 ? nt * (NT / 2) : nt * NT;
     const int wt0 = wave * MT * 16;
     const int tix0 = seg * tpw;
@@ -508,12 +511,23 @@ static hipError_t conv_bf16_launch_t(ConvArgs a, hipStream_t s) {
     if (phase2 && (NW % 2) != 0) return hipErrorInvalidValue;
     const int nTT = (a.Tout + TT - 1) / TT, nNT = phase2 ? (a.N + NT / 2 - 1) / (NT / 2) : (a.N + NT - 1) / NT;
     const int tpw = phase2 ? 1 : bf16_tpw(a, TT, NT, NCK);
-    auto kern = tpw > 1 ? conv_bf16_kernel<MT, NW, true> : conv_bf16_kernel<MT, NW, false>;
-    static size_t lds_allowed[2] = {64 * 1024, 64 * 1024};
-    if (lds > lds_allowed[tpw > 1]) {
+    const bool deint = a.loader == LOADER_DEINT;
+    if (phase2 && deint) return hipErrorInvalidValue;
+    void (*kern)(ConvArgs, int, int, int, int, int);
+    if constexpr ((NW % 2) == 0) {
+        kern = phase2 ? conv_bf16_kernel<MT, NW, false, 2>
+                      : (tpw > 1 ? (deint ? conv_bf16_kernel<MT, NW, true, 1> : conv_bf16_kernel<MT, NW, true, 0>)
+                                 : (deint ? conv_bf16_kernel<MT, NW, false, 1> : conv_bf16_kernel<MT, NW, false, 0>));
+    } else {
+        kern = tpw > 1 ? (deint ? conv_bf16_kernel<MT, NW, true, 1> : conv_bf16_kernel<MT, NW, true, 0>)
+                       : (deint ? conv_bf16_kernel<MT, NW, false, 1> : conv_bf16_kernel<MT, NW, false, 0>);
+    }
+    static size_t lds_allowed[6] = {64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024};
+    const int ki = (tpw > 1 ? 3 : 0) + (phase2 ? 2 : (deint ? 1 : 0));
+    if (lds > lds_allowed[ki]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        lds_allowed[tpw > 1] = lds;
+        lds_allowed[ki] = lds;
     }
     const long long nseg = ((long long)nTT * a.B + tpw - 1) / tpw;
     const long long grid = nseg * nNT;
