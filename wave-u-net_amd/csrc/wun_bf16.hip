@@ -57,20 +57,16 @@ template <int MT> struct BfXit { static constexpr int v = MT == 4 ? 9 : (MT == 2
 // lane: no registers, the image is already in LDS order); the input window is fetched into registers while
 // the previous MFMAs run and written (bf16-rounded) afterwards.
 //
-// Two schedules, chosen by the launcher:
-//   * S > 1 stages (wide layers): one output tile per workgroup; weights and input of stage s+1 stream in
-//     while stage s computes (both double-buffered);
-//   * S == 1 (all input channels fit one stage -- the shallow, long layers that carry most of the FLOPs and
-//     all of the HBM traffic): WEIGHTS-STATIONARY.  A workgroup loads its column tile's weights once and
-//     walks `tpw` consecutive time tiles; the input window of tile i+1 streams in (double-buffered) while
-//     tile i computes and stores, so a tile costs its MFMAs, not a dependent chain of memory round trips.
+// One output tile per workgroup; with S > 1 stages the weights and the input window of stage s+1 stream in while
+// stage s computes (both double-buffered).  (A weights-stationary walk over several time tiles of one column tile was
+// built and measured -- no gain on the one-stage layers it applies to -- and removed.)
 // MODE: 0 stride-1 loader, 1 stride-2 (even / odd planes) loader, 2 fused two-phase transposed conv (stride-1 loader).
 // Compile-time, like the schedule: at bf16 MFMA rates the narrow layers are bound by the instruction stream around the
 // MFMAs, and four uniform run-time branches in the stage loop were measured to cost them 4 %.
-template <int MT, int NW, bool WS, int MODE>
-__global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int nNT, int NCK, int ROWS, int tpw_arg) {
-    const int tpw = WS ? tpw_arg : 1;                       // WS: weights-stationary walk over tpw time tiles (own instantiation:
-                                                            // the one-tile kernel must not pay its registers)
+// NCK (chunks of 32 input channels per stage: 1..3) is compile-time as well: row pitch, slab sizes and the k-step walk
+// of the MFMA loop become immediates.
+template <int MT, int NW, int MODE, int NCK>
+__global__ __launch_bounds__(256, (MT == 4 ? 2 : (MT == 2 ? (NW <= 3 ? 3 : 2) : (NW <= 3 ? 4 : 3)))) void conv_bf16_kernel(ConvArgs a, int nTT, int nNT, int ROWS) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int WT = 4;
     constexpr int TT = WT * MT * 16;
@@ -79,15 +75,15 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
     constexpr bool deint = MODE == 1;
     constexpr int planes = deint ? 2 : 1;
     const int KW = a.KW;
-    const int XPB = 64 * NCK + 32;                          // bytes per X row: conflict-free for ds_read_b128 at every tap
-    const int C8S = 4 * NCK;                                // 8-channel groups per stage
+    constexpr int XPB = 64 * NCK + 32;                      // bytes per X row: conflict-free for ds_read_b128 at every tap
+    constexpr int C8S = 4 * NCK;                            // 8-channel groups per stage
     const int Ctot = a.C0 + a.C1;
-    const int CKW = 32 * NCK;
+    constexpr int CKW = 32 * NCK;
     const int S = (Ctot + CKW - 1) / CKW;
 
     const int xbytes = planes * ROWS * XPB;
     const int wbytes = KW * C8S * NT * 16;
-    const int nxb = (S > 1 || tpw > 1) ? 2 : 1;             // X buffers; W buffers: 2 only when there are several stages
+    const int nxb = S > 1 ? 2 : 1;                          // X / W buffers: 2 only when there are several stages
     unsigned char* Xs = smem;
     unsigned char* Ws = smem + nxb * xbytes;
 
@@ -104,9 +100,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
     constexpr bool phase2 = MODE == 2;
     const int n0 = phase2 ? nt * (NT / 2) : nt * NT;
     const int wt0 = wave * MT * 16;
-    const int tix0 = seg * tpw;
-    int tix1 = tix0 + tpw;
-    if (tix1 > a.B * nTT) tix1 = a.B * nTT;
+    const int tix0 = seg;
 
     f32x4 acc[MT][NW];
     float xreg[XIT][8];
@@ -193,7 +187,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
     };
     // ---- W: packed bf16 image [KW][C8p][Npad][8] -> LDS [tap][channel group][cout][8], 16 bytes per lane ----
     const unsigned short* Wb = reinterpret_cast<const unsigned short*>(a.W);
-    const int per_tap = C8S * NT;                           // 16-byte items per tap (<= 768)
+    constexpr int per_tap = C8S * NT;                       // 16-byte items per tap (<= 768)
     int wofs[3];                                            // tap-invariant element offset of this lane's items
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -381,9 +375,6 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
             for (int n = 0; n < NW; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     };
 
-    // One loop serves both schedules (single call site per phase keeps the code and register footprint small):
-    //   S > 1 : tpw == 1, the inner stage loop double-buffers weights + input window;
-    //   S == 1: weights stay, the tile loop double-buffers the input window of the next tile.
     int b, q0;
     // diagnostic switches (WUN_BF_ABL, uniform; only in builds with -DWUN_BF_ABLATION -- the extra branches cost the
     // narrow layers 4 %): 1 no MFMA, 2 no epilogue, 4 no input staging, 8 no weight DMA
@@ -396,42 +387,21 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvArgs a, int nTT, int
     if (!ab_now) dma_w(0, 0);
     if (!ab_nox) { load_x(0); store_x(0, 0); }
     __syncthreads();
-    if constexpr (!WS) {
-        // ---- one output tile: weights and input window of stage st+1 stream in under the MFMAs of stage st ----
-        zero_acc();
-        for (int st = 0; st < S; ++st) {
-            const bool has_next = st + 1 < S;
-            if (has_next) {
-                if (!ab_now) dma_w(st + 1, (st + 1) & 1);
-                if (!ab_nox) load_x(st + 1);
-            }
-            if (!ab_nomfma) run_stage(st & 1, st & 1);
-            if (has_next) {
-                if (!ab_nox) store_x(st + 1, (st + 1) & 1);
-                __syncthreads();
-            }
+    // ---- one output tile: weights and input window of stage st+1 stream in under the MFMAs of stage st ----
+    zero_acc();
+    for (int st = 0; st < S; ++st) {
+        const bool has_next = st + 1 < S;
+        if (has_next) {
+            if (!ab_now) dma_w(st + 1, (st + 1) & 1);
+            if (!ab_nox) load_x(st + 1);
         }
-        if (!ab_noepi) epilogue(b, q0);
-    } else {
-        // ---- weights-stationary (S == 1): walk this workgroup's time tiles, input window double-buffered ----
-        int xb = 0;
-        for (int tix = tix0; tix < tix1; ++tix) {
-            const int bc = b, qc = q0;
-            const bool next_tile = tix + 1 < tix1;
-            zero_acc();
-            if (next_tile) {
-                set_tile(tix + 1, b, q0);
-                if (!ab_nox) load_x(0);
-            }
-            if (!ab_nomfma) run_stage(xb, 0);
-            if (!ab_noepi) epilogue(bc, qc);
-            if (next_tile) {
-                store_x(0, xb ^ 1);
-                __syncthreads();
-                xb ^= 1;
-            }
+        if (!ab_nomfma) run_stage(st & 1, st & 1);
+        if (has_next) {
+            if (!ab_nox) store_x(st + 1, (st + 1) & 1);
+            __syncthreads();
         }
     }
+    if (!ab_noepi) epilogue(b, q0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -460,26 +430,10 @@ static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) 
 static inline int bf16_rows(const ConvArgs& a, int TT) {
     return a.loader == LOADER_DEINT ? TT + (a.KW + 1) / 2 : TT + a.KW - 1;
 }
-// tiles per workgroup in the weights-stationary schedule (one stage): enough workgroups for two rounds on 256 CUs
-static inline int bf16_tpw(const ConvArgs& a, int TT, int NT, int nck) {
-    const int S = (a.C0 + a.C1 + 32 * nck - 1) / (32 * nck);
-    if (S > 1) return 1;
-    // the tile walk only pays when the epilogue issues no loads (no mask / accumulate: forward convs) -- a load there
-    // waits on vmcnt(0) and drains the next tile's input prefetch
-    if (a.msk0 != nullptr || a.msk1 != nullptr || (a.flags & F_ACCUM)) return 1;
-    static const int enable = getenv("WUN_BF16_STATIONARY") ? atoi(getenv("WUN_BF16_STATIONARY")) : 0;
-    if (!enable) return 1;
-    const long long jobs = (long long)((a.Tout + TT - 1) / TT) * a.B;          // time tiles per column tile
-    const long long cols = (a.N + NT - 1) / NT;
-    long long tpw = (jobs * cols + 511) / 512;
-    if (tpw < 1) tpw = 1;
-    if (tpw > 64) tpw = 64;
-    return (int)tpw;
-}
 static inline size_t bf16_lds(const ConvArgs& a, int TT, int NT, int nck) {
     const int planes = a.loader == LOADER_DEINT ? 2 : 1;
     const int S = (a.C0 + a.C1 + 32 * nck - 1) / (32 * nck);
-    const int nxb = (S > 1 || bf16_tpw(a, TT, NT, nck) > 1) ? 2 : 1, nwb = S > 1 ? 2 : 1;
+    const int nxb = S > 1 ? 2 : 1, nwb = S > 1 ? 2 : 1;
     return nxb * ((size_t)planes * bf16_rows(a, TT) * (64 * nck + 32)) + nwb * ((size_t)a.KW * 4 * nck * NT * 16);
 }
 // channel chunks per stage: enough tap-chunks (~12) per stage to cover a memory round trip, within the
@@ -499,47 +453,52 @@ static int bf16_pick_nck(const ConvArgs& a, int TT, int NT, int xit) {
     return nck;
 }
 
+template <int MT, int NW, int MODE, int NCK>
+static hipError_t conv_bf16_launch_k(const ConvArgs& a, int nTT, int nNT, int ROWS, size_t lds, long long grid, hipStream_t s) {
+    auto kern = conv_bf16_kernel<MT, NW, MODE, NCK>;
+    static size_t lds_allowed = 64 * 1024;
+    if (lds > lds_allowed) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_allowed = lds;
+    }
+    char nm[64], tag[160];
+    snprintf(nm, sizeof(nm), "conv_bf16_kernel<%d, %d>", MT, NW);
+    snprintf(tag, sizeof(tag), "C=%d N=%d T=%d K=%d ld=%d B=%d nck=%d ph2=%d grid=%lld", a.C0 + a.C1, a.N, a.Tout, a.KW, a.loader,
+             a.B, NCK, MODE == 2 ? 1 : 0, grid);
+    prof_scope_begin(nm, conv_flops(a), s, tag);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a, nTT, nNT, ROWS);
+    prof_scope_end(s);
+    return hipGetLastError();
+}
+
+template <int MT, int NW, int MODE>
+static hipError_t conv_bf16_launch_m(const ConvArgs& a, int NCK, int nTT, int nNT, int ROWS, size_t lds, long long grid, hipStream_t s) {
+    if (NCK == 1) return conv_bf16_launch_k<MT, NW, MODE, 1>(a, nTT, nNT, ROWS, lds, grid, s);
+    if (NCK == 2) return conv_bf16_launch_k<MT, NW, MODE, 2>(a, nTT, nNT, ROWS, lds, grid, s);
+    if (NCK == 3) return conv_bf16_launch_k<MT, NW, MODE, 3>(a, nTT, nNT, ROWS, lds, grid, s);
+    return hipErrorInvalidValue;
+}
+
 template <int MT, int NW>
 static hipError_t conv_bf16_launch_t(ConvArgs a, hipStream_t s) {
     constexpr int TT = 4 * MT * 16, NT = NW * 16;
     const int NCK = bf16_pick_nck(a, TT, NT, BfXit<MT>::v);
     const int ROWS = bf16_rows(a, TT);
-    const int planes = a.loader == LOADER_DEINT ? 2 : 1;
+    const bool deint = a.loader == LOADER_DEINT;
+    const int planes = deint ? 2 : 1;
     const size_t lds = bf16_lds(a, TT, NT, NCK);
     if (lds > 160 * 1024 || ((planes * ROWS + 63) & ~63) * 4 * NCK > BfXit<MT>::v * 256) return hipErrorInvalidValue;
     const bool phase2 = (a.flags & F_PHASE2) != 0;
-    if (phase2 && (NW % 2) != 0) return hipErrorInvalidValue;
+    if (phase2 && ((NW % 2) != 0 || deint)) return hipErrorInvalidValue;
     const int nTT = (a.Tout + TT - 1) / TT, nNT = phase2 ? (a.N + NT / 2 - 1) / (NT / 2) : (a.N + NT - 1) / NT;
-    const int tpw = phase2 ? 1 : bf16_tpw(a, TT, NT, NCK);
-    const bool deint = a.loader == LOADER_DEINT;
-    if (phase2 && deint) return hipErrorInvalidValue;
-    void (*kern)(ConvArgs, int, int, int, int, int);
-    if constexpr ((NW % 2) == 0) {
-        kern = phase2 ? conv_bf16_kernel<MT, NW, false, 2>
-                      : (tpw > 1 ? (deint ? conv_bf16_kernel<MT, NW, true, 1> : conv_bf16_kernel<MT, NW, true, 0>)
-                                 : (deint ? conv_bf16_kernel<MT, NW, false, 1> : conv_bf16_kernel<MT, NW, false, 0>));
-    } else {
-        kern = tpw > 1 ? (deint ? conv_bf16_kernel<MT, NW, true, 1> : conv_bf16_kernel<MT, NW, true, 0>)
-                       : (deint ? conv_bf16_kernel<MT, NW, false, 1> : conv_bf16_kernel<MT, NW, false, 0>);
-    }
-    static size_t lds_allowed[6] = {64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024};
-    const int ki = (tpw > 1 ? 3 : 0) + (phase2 ? 2 : (deint ? 1 : 0));
-    if (lds > lds_allowed[ki]) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        lds_allowed[ki] = lds;
-    }
-    const long long nseg = ((long long)nTT * a.B + tpw - 1) / tpw;
-    const long long grid = nseg * nNT;
+    const long long grid = (long long)nTT * a.B * nNT;
     if (grid <= 0) return hipSuccess;
-    char nm[64], tag[160];
-    snprintf(nm, sizeof(nm), "conv_bf16_kernel<%d, %d%s>", MT, NW, tpw > 1 ? ", ws" : "");
-    snprintf(tag, sizeof(tag), "C=%d N=%d T=%d K=%d ld=%d B=%d nck=%d tpw=%d grid=%lld", a.C0 + a.C1, a.N, a.Tout, a.KW, a.loader,
-             a.B, NCK, tpw, grid);
-    prof_scope_begin(nm, conv_flops(a), s, tag);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a, nTT, nNT, NCK, ROWS, tpw);
-    prof_scope_end(s);
-    return hipGetLastError();
+    if constexpr ((NW % 2) == 0) {
+        if (phase2) return conv_bf16_launch_m<MT, NW, 2>(a, NCK, nTT, nNT, ROWS, lds, grid, s);
+    }
+    return deint ? conv_bf16_launch_m<MT, NW, 1>(a, NCK, nTT, nNT, ROWS, lds, grid, s)
+                 : conv_bf16_launch_m<MT, NW, 0>(a, NCK, nTT, nNT, ROWS, lds, grid, s);
 }
 
 // a.W must point at the packed bf16 image of the layer's weights (pack_bf16_kernel), a.wb_c8p / a.wb_npad set
