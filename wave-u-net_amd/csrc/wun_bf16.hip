@@ -65,8 +65,11 @@ template <int MT> struct BfXit { static constexpr int v = MT == 4 ? 9 : (MT == 2
 // MFMAs, and four uniform run-time branches in the stage loop were measured to cost them 4 %.
 // NCK (chunks of 32 input channels per stage: 1..3) is compile-time as well: row pitch, slab sizes and the k-step walk
 // of the MFMA loop become immediates.
-template <int MT, int NW, int MODE, int NCK>
-__global__ __launch_bounds__(256, (MT == 4 ? 2 : (MT == 2 ? (NW <= 3 ? 3 : 2) : (NW <= 3 ? 4 : 3)))) void conv_bf16_kernel(ConvArgs a, int nTT, int nNT, int ROWS) {
+// KT: the tap count when it is one of the reference's shipped filter sizes (15 / 5, 8 = a phase of the transposed
+// 15-tap conv), 0 = run-time taps: tap loops, slab sizes and the row count of the input window are then constants too.
+template <int MT, int NW, int MODE, int NCK, int KT>
+__global__ __launch_bounds__(256, (MT == 4 ? 2 : (MT == 2 ? (NW <= 3 ? 3 : 2) : (NW <= 3 ? 4 : 3)))) void conv_bf16_kernel(ConvArgs a, int nTT, int nNT, int ROWS_arg) {
+    const int ROWS = KT > 0 ? (MODE == 1 ? 4 * MT * 16 + (KT + 1) / 2 : 4 * MT * 16 + KT - 1) : ROWS_arg;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int WT = 4;
     constexpr int TT = WT * MT * 16;
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256, (MT == 4 ? 2 : (MT == 2 ? (NW <= 3 ? 3 : 2) : 
     constexpr int XIT = BfXit<MT>::v;
     constexpr bool deint = MODE == 1;
     constexpr int planes = deint ? 2 : 1;
-    const int KW = a.KW;
+    const int KW = KT > 0 ? KT : a.KW;
     constexpr int XPB = 64 * NCK + 32;                      // bytes per X row: conflict-free for ds_read_b128 at every tap
     constexpr int C8S = 4 * NCK;                            // 8-channel groups per stage
     const int Ctot = a.C0 + a.C1;
@@ -236,6 +239,7 @@ __global__ __launch_bounds__(256, (MT == 4 ? 2 : (MT == 2 ? (NW <= 3 ? 3 : 2) : 
         int j = 0, sc = 0;
         auto advance = [&]() { if (++sc == NCK) { sc = 0; ++j; } };
         ldops(0, 0, a0, b0);
+#pragma unroll 1                                             // (fully unrolled, 30-45 k-steps of hoisted LDS reads spill)
         for (int i = 0; i < nsteps; i += 2) {
             advance();
             if (i + 1 < nsteps) ldops(j, sc, a1, b1);
@@ -453,9 +457,9 @@ static int bf16_pick_nck(const ConvArgs& a, int TT, int NT, int xit) {
     return nck;
 }
 
-template <int MT, int NW, int MODE, int NCK>
+template <int MT, int NW, int MODE, int NCK, int KT>
 static hipError_t conv_bf16_launch_k(const ConvArgs& a, int nTT, int nNT, int ROWS, size_t lds, long long grid, hipStream_t s) {
-    auto kern = conv_bf16_kernel<MT, NW, MODE, NCK>;
+    auto kern = conv_bf16_kernel<MT, NW, MODE, NCK, KT>;
     static size_t lds_allowed = 64 * 1024;
     if (lds > lds_allowed) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -474,9 +478,17 @@ static hipError_t conv_bf16_launch_k(const ConvArgs& a, int nTT, int nNT, int RO
 
 template <int MT, int NW, int MODE>
 static hipError_t conv_bf16_launch_m(const ConvArgs& a, int NCK, int nTT, int nNT, int ROWS, size_t lds, long long grid, hipStream_t s) {
-    if (NCK == 1) return conv_bf16_launch_k<MT, NW, MODE, 1>(a, nTT, nNT, ROWS, lds, grid, s);
-    if (NCK == 2) return conv_bf16_launch_k<MT, NW, MODE, 2>(a, nTT, nNT, ROWS, lds, grid, s);
-    if (NCK == 3) return conv_bf16_launch_k<MT, NW, MODE, 3>(a, nTT, nNT, ROWS, lds, grid, s);
+    // the shipped filter sizes get their own instantiation: stride-1 loader 15 / 5 taps, stride-2 loader 15 taps, the
+    // fused two-phase conv 8 taps per phase (of 15); anything else takes the run-time-tap kernel
+    constexpr int K1 = MODE == 2 ? 8 : 15, K2 = MODE == 0 ? 5 : 0;
+#define WUN_BF_K(N) \
+    if (NCK == N) { \
+        if (a.KW == K1) return conv_bf16_launch_k<MT, NW, MODE, N, K1>(a, nTT, nNT, ROWS, lds, grid, s); \
+        if (K2 > 0 && a.KW == K2) return conv_bf16_launch_k<MT, NW, MODE, N, K2>(a, nTT, nNT, ROWS, lds, grid, s); \
+        return conv_bf16_launch_k<MT, NW, MODE, N, 0>(a, nTT, nNT, ROWS, lds, grid, s); \
+    }
+    WUN_BF_K(1) WUN_BF_K(2) WUN_BF_K(3)
+#undef WUN_BF_K
     return hipErrorInvalidValue;
 }
 
