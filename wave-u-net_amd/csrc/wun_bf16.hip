@@ -493,9 +493,9 @@ static hipError_t conv_bf16_launch_m(const ConvArgs& a, int NCK, int nTT, int nN
 }
 
 template <int MT, int NW>
-static hipError_t conv_bf16_launch_t(ConvArgs a, hipStream_t s) {
+static hipError_t conv_bf16_launch_t(ConvArgs a, hipStream_t s, int nck_force = 0) {
     constexpr int TT = 4 * MT * 16, NT = NW * 16;
-    const int NCK = bf16_pick_nck(a, TT, NT, BfXit<MT>::v);
+    const int NCK = nck_force > 0 ? nck_force : bf16_pick_nck(a, TT, NT, BfXit<MT>::v);
     const int ROWS = bf16_rows(a, TT);
     const bool deint = a.loader == LOADER_DEINT;
     const int planes = deint ? 2 : 1;
@@ -513,6 +513,32 @@ static hipError_t conv_bf16_launch_t(ConvArgs a, hipStream_t s) {
                  : conv_bf16_launch_m<MT, NW, 0>(a, NCK, nTT, nNT, ROWS, lds, grid, s);
 }
 
+// Tile choices of the autotuner: code = (log2 MT) * 9 + (NW - 2) * 3 + (NCK - 1), MT in {1, 2, 4} tiles of 16
+// positions per wave, NW in {2, 3, 4} column tiles, NCK in {1, 2, 3} channel chunks per stage.
+bool conv_bf16_choice_ok(const ConvArgs& a, int variant) {
+    const int code = variant - kBf16VariantBase;
+    if (code < 0 || code >= 27 || !conv_bf16_supported(a)) return false;
+    const int mt = 1 << (code / 9), nw = 2 + (code / 3) % 3, nck = 1 + code % 3;
+    const bool phase2 = (a.flags & F_PHASE2) != 0;
+    if (phase2 && (nw & 1)) return false;
+    const int TT = 64 * mt, NT = 16 * nw;
+    const int chan = phase2 ? NT / 2 : NT;
+    const int padded = (a.N + chan - 1) / chan * chan;
+    if (padded * 3 > a.N * 4 + 48) return false;                       // > ~33 % padded columns
+    if (TT > 64 && TT >= 2 * a.Tout) return false;                     // mostly padding in time
+    if (nck > (a.C0 + a.C1 + 31) / 32) return false;
+    const int planes = a.loader == LOADER_DEINT ? 2 : 1;
+    const int xit = mt == 4 ? 9 : (mt == 2 ? 7 : 4);
+    if (((planes * bf16_rows(a, TT) + 63) & ~63) * 4 * nck > xit * 256) return false;
+    return bf16_lds(a, TT, NT, nck) <= 160 * 1024;
+}
+int conv_bf16_list_candidates(const ConvArgs& a, ConvChoice* out, int maxn) {
+    int n = 0;
+    for (int code = 0; code < 27 && n < maxn; ++code)
+        if (conv_bf16_choice_ok(a, kBf16VariantBase + code)) { out[n].variant = kBf16VariantBase + code; out[n].ksplit = 1; ++n; }
+    return n;
+}
+
 // a.W must point at the packed bf16 image of the layer's weights (pack_bf16_kernel), a.wb_c8p / a.wb_npad set
 hipError_t launch_conv_bf16(const ConvArgs& a_in, hipStream_t s) {
     ConvArgs a = a_in;
@@ -524,6 +550,18 @@ hipError_t launch_conv_bf16(const ConvArgs& a_in, hipStream_t s) {
     if (a.dec != nullptr) vec = vec && (a.decpitch & 1) == 0 && (a.decbs & 1) == 0;
     if (vec) a.flags |= F_VEC4;
     if (const char* e = getenv("WUN_BF_ABL")) a.flags |= atoi(e) << 16;      // diagnostic: skip phases of the kernel
+    // autotuned choice (ConvChoice.variant = kBf16VariantBase + tile code; checked by conv_bf16_choice_ok)
+    if (a.force_variant > kBf16VariantBase) {
+        const int code = a.force_variant - 1 - kBf16VariantBase;
+        if (!conv_bf16_choice_ok(a, a.force_variant - 1)) return hipErrorInvalidValue;
+        const int mt = 1 << (code / 9), nw = 2 + (code / 3) % 3, nck = 1 + code % 3;
+#define WUN_BF(M, N) if (mt == M && nw == N) return conv_bf16_launch_t<M, N>(a, s, nck);
+        WUN_BF(4, 4) WUN_BF(4, 3) WUN_BF(4, 2)
+        WUN_BF(2, 4) WUN_BF(2, 3) WUN_BF(2, 2)
+        WUN_BF(1, 4) WUN_BF(1, 3) WUN_BF(1, 2)
+#undef WUN_BF
+        return hipErrorInvalidValue;
+    }
     // tile: fewest padded columns among 64/48/32; rows by how many tiles the launch has
     const bool phase2 = (a.flags & F_PHASE2) != 0;
     int bestnw = 4, bestpad = 1 << 30;

@@ -102,6 +102,10 @@ struct NarrowWgradArgs {
 };
 
 struct ConvChoice { int variant; int ksplit; };
+// bf16 conv (wun_bf16.hip): tile choices share the tuning tables with the fp32 variants, offset by kBf16VariantBase
+static const int kBf16VariantBase = 1000;
+bool conv_bf16_choice_ok(const ConvArgs& a, int variant);
+int conv_bf16_list_candidates(const ConvArgs& a, ConvChoice* out, int maxn);
 struct WgradChoice { int mtw, nw, nsplit[2]; };   // per layer: shared tile geometry, split count per part
 
 struct UpsampleArgs {

@@ -603,6 +603,28 @@ static hipError_t conv_dispatch(const wun_plan* p, ConvArgs a, float* part, long
         if (it != p->bf_img.end()) {
             a.W = p->cur_ws + it->second.off;
             a.wb_c8p = it->second.c8p; a.wb_npad = it->second.npad;
+            // tile (positions x columns x channel chunks per stage) autotuned like the fp32 variants
+            if (p->tune_mode == 1) {
+                if (vec.size() <= idx) vec.resize(idx + 1, ConvChoice{-1, 0});
+                ConvChoice cands[32];
+                const int n = conv_bf16_list_candidates(a, cands, 32);
+                float best = time_launch(p, s, [&]() { return launch_conv_bf16(a, s); });
+                const float base = best;
+                ConvChoice bc{-1, 0};
+                for (int i = 0; i < n; ++i) {
+                    ConvArgs b = a;
+                    b.force_variant = cands[i].variant + 1;
+                    const float ms = time_launch(p, s, [&]() { return launch_conv_bf16(b, s); });
+                    if (ms < best * 0.98f) { best = ms; bc = cands[i]; }
+                }
+                vec[idx] = bc;
+                if (getenv("WUN_TUNE_LOG"))
+                    fprintf(stderr, "[tune conv-bf16 %s#%zu] C=%d N=%d T=%d K=%d ld=%d ph2=%d cands=%d base %.3f ms -> code=%d %.3f ms\n",
+                            p->in_bwd ? "bwd" : "fwd", idx, a.C0 + a.C1, a.N, a.Tout, a.KW, a.loader, (a.flags & F_PHASE2) ? 1 : 0, n,
+                            base, bc.variant, best);
+            }
+            if (p->tune_mode >= 1 && idx < vec.size() && vec[idx].variant >= kBf16VariantBase && conv_bf16_choice_ok(a, vec[idx].variant))
+                a.force_variant = vec[idx].variant + 1;
             return launch_conv_bf16(a, s);
         }
     }
@@ -1304,10 +1326,11 @@ extern "C" int wun_plan_tune_import(const wun_plan* p, const char* text) {
         return fail(WUN_ERR_INVALID, "truncated tuning table");
     for (const std::vector<ConvChoice>* v : {&cf, &cb})
         for (const ConvChoice& c : *v)
-            if (c.variant < -1 || c.variant >= nvar || c.ksplit < 0 || c.ksplit > 64)
+            if (c.variant < -1 || (c.variant >= nvar && !(c.variant >= kBf16VariantBase && c.variant < kBf16VariantBase + 27)) ||
+                c.ksplit < 0 || c.ksplit > 64)
                 return fail(WUN_ERR_INVALID, "tuning table entry out of range");
     for (const WgradChoice& c : wg)
-        if (c.nsplit[0] < 0 || c.nsplit[1] < 0 || c.mtw < 0 || c.mtw > 6 || c.nw < 0 || c.nw > 5)
+        if (c.nsplit[0] < 0 || c.nsplit[1] < 0 || c.mtw < 0 || c.mtw > 8 || c.nw < 0 || c.nw > 5)
             return fail(WUN_ERR_INVALID, "tuning table entry out of range");
     // (whether each entry is a legal choice for the launch at its position is checked when it is used)
     p->conv_fwd = cf; p->conv_bwd = cb; p->wg_bwd = wg;
