@@ -1631,7 +1631,44 @@ __global__ void upsample_kernel(UpsampleArgs a) {
     }
 }
 
+// Vector form (rows 16-byte aligned: the plan's buffers): block = 4 (b, c) rows x 64 lanes, a lane produces 4
+// consecutive outputs from x[2i], x[2i+1], x[2i+2] -- one 8-byte + one 4-byte load, one 16-byte store, no integer
+// division (the scalar kernel spends its time on three 64-bit divisions per element).  Same arithmetic per element.
+__global__ __launch_bounds__(256) void upsample_vec_kernel(UpsampleArgs a) {
+    const int row = (int)blockIdx.y * 4 + (int)(threadIdx.x >> 6);
+    const int i = (int)blockIdx.x * 64 + (int)(threadIdx.x & 63);          // vector index: outputs 4i .. 4i+3
+    if (row >= a.B * a.C || 4 * i >= a.tup) return;
+    const int b = row / a.C, c = row - b * a.C;
+    const float* x = a.x + (long long)b * a.xbs + (long long)c * a.xpitch;
+    float* y = a.y + (long long)b * a.ybs + (long long)c * a.ypitch;
+    const int j = 2 * i;
+    const float x0 = x[j];
+    const float x1r = (j + 1 < a.n) ? x[j + 1] : 0.f, x2r = (j + 2 < a.n) ? x[j + 2] : 0.f;
+    float o1, o3;
+    if (a.w != nullptr) {
+        const float sg = 1.f / (1.f + __expf(-a.w[c]));
+        o1 = sg * x0 + (1.f - sg) * x1r;                                    // SAME: one zero on the right
+        o3 = sg * x1r + (1.f - sg) * x2r;
+    } else {
+        o1 = 0.5f * (x0 + ((j + 1 < a.n) ? x1r : x0));                      // legacy bilinear clamps
+        o3 = 0.5f * (x1r + ((j + 2 < a.n) ? x2r : x1r));
+    }
+    const int t = 4 * i;
+    if (t + 3 < a.tup) {
+        *reinterpret_cast<f32x4*>(y + t) = (f32x4){x0, o1, x1r, o3};
+    } else {
+        y[t] = x0;
+        if (t + 1 < a.tup) y[t + 1] = o1;
+        if (t + 2 < a.tup) y[t + 2] = x1r;
+    }
+}
+
 hipError_t launch_upsample(const UpsampleArgs& a, hipStream_t s) {
+    if ((a.ypitch & 3) == 0 && (a.ybs & 3) == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0 && (long long)a.B * a.C <= 4 * 65535ll) {
+        const int nvec = (a.tup + 3) / 4;
+        hipLaunchKernelGGL(upsample_vec_kernel, dim3((unsigned)((nvec + 63) / 64), (unsigned)((a.B * a.C + 3) / 4)), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     const long long total = (long long)a.B * a.C * a.tup;
     long long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
@@ -1689,11 +1726,67 @@ __global__ __launch_bounds__(256) void interp_grad_kernel(UpsampleBwdArgs a) {
     }
 }
 
+// Vector form of upsample_bwd_kernel: a lane produces dz[4i .. 4i+3] from dy[8i-1 .. 8i+7] (two 16-byte loads + one
+// scalar) and the mask vector; same arithmetic and summation order per element.
+__global__ __launch_bounds__(256) void upsample_bwd_vec_kernel(UpsampleBwdArgs a) {
+    const int row = (int)blockIdx.y * 4 + (int)(threadIdx.x >> 6);
+    const int iv = (int)blockIdx.x * 64 + (int)(threadIdx.x & 63);         // vector index: dz[4iv .. 4iv+3]
+    if (row >= a.B * a.C || 4 * iv >= a.n) return;
+    const int b = row / a.C, c = row - b * a.C;
+    const float* dy = a.dy + (long long)b * a.ybs + (long long)c * a.ypitch;
+    float wa = 0.5f, wb = 0.5f;
+    if (a.w != nullptr) { wa = 1.f / (1.f + __expf(-a.w[c])); wb = 1.f - wa; }
+    float d[9];                                                             // d[k] = dy[8iv - 1 + k] (0 outside)
+    const int t0 = 8 * iv;
+    d[0] = (t0 >= 1) ? dy[t0 - 1] : 0.f;
+    if (t0 + 7 < a.tup) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(dy + t0), v1 = *reinterpret_cast<const f32x4*>(dy + t0 + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { d[1 + k] = v0[k]; d[5 + k] = v1[k]; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[1 + k] = (t0 + k < a.tup) ? dy[t0 + k] : 0.f;
+    }
+    const long long xi = (long long)b * a.xbs + (long long)c * a.xpitch + 4 * iv;
+    float g[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = 4 * iv + k;
+        float v = d[1 + 2 * k];                                             // dy[2i]
+        if (2 * i + 1 < a.tup) {
+            float wgt = wa;
+            if (a.w == nullptr && i == a.n - 1) wgt = 1.f;                  // same-mode legacy clamp: out[2n-1] = x[n-1]
+            v += wgt * d[2 + 2 * k];
+        }
+        if (i >= 1) v += wb * d[2 * k];
+        g[k] = v;
+    }
+    if (4 * iv + 3 < a.n) {
+        const f32x4 xm = *reinterpret_cast<const f32x4*>(a.x + xi);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = g[k] * ((xm[k] > 0.f) ? 1.f : 0.2f);
+        *reinterpret_cast<f32x4*>(a.dz + xi) = o;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (4 * iv + k < a.n) a.dz[xi + k] = g[k] * ((a.x[xi + k] > 0.f) ? 1.f : 0.2f);
+    }
+}
+
 hipError_t launch_upsample_bwd(const UpsampleBwdArgs& a, hipStream_t s) {
     const long long total = (long long)a.B * a.C * a.n;
     long long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    const bool vecok = (a.ypitch & 3) == 0 && (a.ybs & 3) == 0 && (reinterpret_cast<uintptr_t>(a.dy) & 15) == 0 &&
+                       (a.xpitch & 3) == 0 && (a.xbs & 3) == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 &&
+                       (reinterpret_cast<uintptr_t>(a.dz) & 15) == 0 && (long long)a.B * a.C <= 4 * 65535ll;
+    if (vecok) {
+        const int nvec = (a.n + 3) / 4;
+        hipLaunchKernelGGL(upsample_bwd_vec_kernel, dim3((unsigned)((nvec + 63) / 64), (unsigned)((a.B * a.C + 3) / 4)), dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (a.w != nullptr && a.dw != nullptr) {
