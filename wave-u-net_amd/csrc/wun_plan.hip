@@ -694,14 +694,18 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
 
     // Context mode: the skip-window conv of level i is only consumed by up level L-1-i, i.e. the windows of the
     // shallow, FLOP-heavy levels are needed LAST.  The deep levels (few positions per excerpt) form a dependent
-    // chain of launch-latency-bound kernels that leaves most CUs idle, so the shallow levels' window convs are
-    // deferred: queued on a third stream once the deep chain starts (deepest-needed first) and awaited per level
-    // by the up path.  They fill the idle CUs instead of competing with their own level's decimating conv.
+    // chain of launch-latency-bound kernels that leaves most CUs idle, so the window convs are deferred: queued on a
+    // third stream (deepest-needed first) and awaited per level by the up path.  They fill the idle CUs instead of
+    // competing with their own level's decimating conv.
     int defer_below = 0;                                            // levels [0, defer_below) are deferred
     hipStream_t s3 = (p->side2 && s2 != s) ? p->side2 : s2;
     if (!same && s3 != s2 && getenv("WUN_NO_DEFER") == nullptr) {
         while (defer_below < L && (long long)p->B * p->dsh[defer_below].t_dec >= 16384) ++defer_below;
         if (L - defer_below < 3) defer_below = 0;                   // no deep chain to hide them under
+        // ... and then the deep levels' (small) window convs are deferred as well: ONE event on the caller's stream
+        // starts all of them instead of one event per level (each event holds the dependent chain for ~6 us); same-box
+        // A/B 9.085 -> 9.04 ms.  (Awaiting the deep ones in groups instead of per level stalls the up path: 9.10-9.16.)
+        if (defer_below > 0 && getenv("WUN_DEFER_SHALLOW_ONLY") == nullptr) defer_below = L;
         if (defer_below > 0 && p->skip_ev.size() < (size_t)L) {
             p->skip_ev.resize(L, nullptr);
             for (auto& e : p->skip_ev)
