@@ -70,6 +70,12 @@ typedef struct wun_config {
                                 /*     on v_mfma_f32_16x16x32_bf16, fp32 accumulate; weights, Adam state,*/
                                 /*     activations in HBM, the audio-input conv and the head stay fp32; weight    */
                                 /*     gradients use bf16 operands too (launches with few positions stay fp32)   */
+    int32_t exclusive_streams;  /* scheduling hint, no effect on results.  1 = nothing else runs on this device  */
+                                /* beside the plan's calls: its side streams get the LOWEST queue priority (they  */
+                                /* fill the gaps of the dependent chain on the caller's stream, ~1 % per step).   */
+                                /* 0 (default) = normal priority -- REQUIRED when collectives (RCCL) or other     */
+                                /* streams share the device: low-priority queues beside a communication stream    */
+                                /* were measured 40 % slower (and a process that ever created them stays slow).   */
 } wun_config;
 
 typedef struct wun_plan wun_plan;

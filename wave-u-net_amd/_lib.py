@@ -11,7 +11,7 @@ class WunConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "num_layers", "num_initial_filters", "filter_size", "merge_filter_size",
         "input_filter_size", "output_filter_size", "upsampling", "output_type", "context",
-        "num_sources", "num_channels", "output_activation", "compute_dtype")]
+        "num_sources", "num_channels", "output_activation", "compute_dtype", "exclusive_streams")]
 
 
 class WunPlanInfo(C.Structure):

@@ -551,9 +551,11 @@ static int side_init(const wun_plan* p) {
     // The side streams carry the off-critical-path work (weight gradients, deferred skip-window convs): lowest queue
     // priority, so their workgroups fill the drain of the dependent chain on the caller's stream instead of sharing the
     // CUs with it (A/B, pinned tilings: 9.32 -> 9.21 ms per step; "high" 9.39).  WUN_SIDE_PRIO=normal|high: experiment switch.
+    // Only with wun_config.exclusive_streams: beside a communication stream (RCCL all-reduce on one GPU, same box) the
+    // low-priority queues made the step 13.1 ms instead of 9.2 -- and a process that has ever created them stays slow.
     int least = 0, greatest = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    int prio = least;
+    int prio = p->cfg.exclusive_streams ? least : 0;
     if (const char* e = getenv("WUN_SIDE_PRIO")) prio = (e[0] == 'l') ? least : (e[0] == 'h') ? greatest : 0;
     HIP_TRY(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, prio));
     if (getenv("WUN_TWO_STREAMS") == nullptr) HIP_TRY(hipStreamCreateWithPriority(&p->side2, hipStreamNonBlocking, prio));

@@ -34,7 +34,8 @@ def _wun_config(cfg):
         cfg["num_layers"], cfg["num_initial_filters"], cfg["filter_size"], cfg["merge_filter_size"],
         cfg["input_filter_size"], cfg["output_filter_size"], _UPS[cfg["upsampling"]],
         _OUT[cfg["output_type"]], 1 if cfg["context"] else 0, len(cfg["source_names"]),
-        1 if cfg["mono_downmix"] else 2, _ACT[cfg["output_activation"]], _DTYPE[cfg.get("compute_dtype", "f32")])
+        1 if cfg["mono_downmix"] else 2, _ACT[cfg["output_activation"]], _DTYPE[cfg.get("compute_dtype", "f32")],
+        1 if cfg.get("exclusive_streams", False) else 0)      # extension key: scheduling hint (wun.h), set by the Trainer
 
 
 class _Plan(object):

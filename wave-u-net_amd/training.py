@@ -46,8 +46,13 @@ class Trainer(object):
     """One process per GPU.  step() = sess.run([separator_solver, ...]) of Training.py:105."""
 
     def __init__(self, model_config, batch_size=None, device=None, seed=1337, bucket_mib=16.0):
-        self.cfg = model_config
         self.rank, self.local_rank, self.world = init_distributed()
+        # Scheduling hint of the plan (include/wun.h): low-priority side streams only when no collective shares the
+        # device -- with a process group initialised (multi-GPU, or bench.py --force-allreduce) they must stay normal.
+        if "exclusive_streams" not in model_config:
+            model_config = dict(model_config)
+            model_config["exclusive_streams"] = not (dist.is_available() and dist.is_initialized())
+        self.cfg = model_config
         if device is None:
             device = "cuda:%d" % (self.local_rank % max(1, torch.cuda.device_count()))
         self.device = torch.device(device)
