@@ -130,3 +130,21 @@ def test_product_never_imports_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "oracle" not in src, fn
+
+
+def test_scheduling_hint_defaults_to_shared_device():
+    """wun_config.exclusive_streams (low-priority side streams) is opt-in: a plan created without the key must assume
+    that collectives may share the device; the key maps to the last field of the config struct and nothing else."""
+    cfg = wun.get_config("baseline")
+    c0 = _wun_config(cfg)
+    assert c0.exclusive_streams == 0
+    c1 = _wun_config(dict(cfg, exclusive_streams=True))
+    assert c1.exclusive_streams == 1
+    for name, _ in c0._fields_:
+        if name != "exclusive_streams":
+            assert getattr(c0, name) == getattr(c1, name)
+    # the header declares the field last, after compute_dtype (the struct is passed by pointer to wun_plan_create)
+    hdr = open(os.path.join(ROOT, "include", "wun.h")).read()
+    body = hdr[hdr.index("typedef struct wun_config"):hdr.index("} wun_config;")]
+    names = [ln.split(";")[0].split()[-1] for ln in body.splitlines() if ln.strip().startswith("int32_t")]
+    assert names == [n for n, _ in c0._fields_]
