@@ -4,16 +4,21 @@ when N > 1) of the M1 12-level Wave-U-Net at BASELINE.json configs[1]: fp32, bat
 ~147k-sample context input (147443 -> 16389 samples), synthetic waveforms resident in HBM.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py ...`)
+  N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+  (the driver's form: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment) or started bare --
+  `python bench.py --gpus N` re-executes itself under torch.distributed.run on 127.0.0.1 (one rank per GPU;
+  on a box with fewer GPUs than ranks the ranks share devices and the exchange runs over gloo).
+  --dry-run stops after process-group initialisation and the tuning-table broadcast (works without a GPU).
 
 One "step" = one `sess.run([separator_solver, ...])` of /root/reference/Training.py:105:
 get_output, MSE loss, full backward, TF-Adam update.  Rank 0 prints ONE JSON line.
 `value` = output samples/s of the whole job (N * B * Tout * K / max-over-ranks time);
 the input-sample rate (N * B * Tin) is reported in `config` for reference.
 
-Tilings: the per-launch tile table is read from profiles/round2_tune_table.txt (override with
-WUN_TUNE_CACHE) when it matches this plan and library build, so the timed launches are the ones the
+Tilings: the per-launch tile table is read (never written) from the committed profiles/*_tune_table.txt of
+the named config when it matches this plan and library build, so the timed launches are the ones the
 committed rocprofv3 / PMC profiles describe; otherwise rank 0 autotunes (untimed) and broadcasts.
+WUN_TUNE_CACHE=<file> is a separate, writable cache.
 Extra objects in the line: `roofline` (kernel FAMILY conv_mfma_kernel, HIP events on the launch
 stream), `parity` (step 0 of the timed inputs vs the fp32 oracle), `cpu_baseline` (that oracle timed
 on the host cores, full batch + a 1-thread figure).
@@ -67,7 +72,83 @@ def usable_cores():
     return max(1, n)
 
 
-PINNED_TUNE_TABLE = os.path.join(ROOT, "profiles", "round2_tune_table.txt")
+# committed, READ-ONLY tuning tables per (named config, batch, dtype); never used as a writable cache
+PINNED_TUNE_TABLES = {
+    ("m1_context", 16, "f32"): os.path.join(ROOT, "profiles", "round2_tune_table.txt"),
+    ("baseline", 16, "f32"): os.path.join(ROOT, "profiles", "round3_tune_table_baseline.txt"),
+}
+PINNED_TUNE_TABLE = PINNED_TUNE_TABLES[("m1_context", 16, "f32")]
+
+
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU of
+    this node, rendezvous on 127.0.0.1 (the reference has no multi-device code: Training.py:103-109 is one process)."""
+    import socket
+    import subprocess
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev < n and "WUN_DIST_BACKEND" not in env:
+        # fewer devices than ranks (a 1-GPU test box, or no GPU at all for --dry-run): RCCL refuses duplicate
+        # devices, so the exchange runs over gloo; everything else is the production path
+        env["WUN_DIST_BACKEND"] = "gloo"
+        log("only %d GPU(s) for %d ranks: ranks share devices, gradient exchange over gloo" % (ndev, n))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """Launcher / rendezvous check: process group up, rank 0's tuning table reaches every rank, one JSON line.
+    Without a GPU only the host side runs (gloo); with one the Trainer is built and the table imported."""
+    from wave_u_net_amd.parallel import init_distributed
+    rank, local, world = init_distributed()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    path = PINNED_TUNE_TABLES.get((args.config, args.batch, args.dtype))
+    table = open(path).read() if (rank == 0 and path and os.path.exists(path)) else None
+    imported = None
+    if torch.cuda.is_available():
+        import wave_u_net_amd as wun
+        from wave_u_net_amd.training import Trainer, synthetic_source
+        cfg = wun.get_config(args.config, **parse_overrides(args.set))
+        tr = Trainer(cfg, batch_size=args.batch, bucket_mib=args.bucket_mib)
+        mix, targets = synthetic_source(cfg, tr.batch, tr.t_in, tr.t_out, tr.device, seed=1337 + tr.rank)()
+        tr.tune(mix, targets, pinned_table=table)
+        imported = tr.tune_source
+        table = tr.tune_table
+    elif world > 1:
+        box = [table]
+        dist.broadcast_object_list(box, src=0)
+        table = box[0]
+    import hashlib
+    sha = hashlib.sha256((table or "").encode()).hexdigest()[:16]
+    shas = [None] * world
+    if world > 1:
+        dist.all_gather_object(shas, sha)
+    else:
+        shas = [sha]
+    if len(set(shas)) != 1:
+        raise SystemExit("ranks disagree on the tuning table: %s" % shas)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "scaling": "weak", "backend": dist.get_backend() if world > 1 else None,
+                          "gpu": bool(torch.cuda.is_available()), "tune_table_sha16": sha, "tilings": imported,
+                          "config": {"named_config": args.config, "parallelism": "dp%d" % world}}), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def parse_overrides(items):
+    out = {}
+    for it in items or []:
+        k, v = it.split("=", 1)
+        try:
+            out[k] = json.loads(v)
+        except ValueError:
+            out[k] = v
+    return out
 
 
 def family_of(kernel_name):
@@ -176,8 +257,8 @@ def cpu_baseline(cfg_over, params, mix, targets, names, gpu, budget_s=45.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="m1_context")
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline (and the parity object)")
@@ -189,15 +270,28 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 = the reference's arithmetic (headline); bf16 = the speed mode of BASELINE.json configs[2],[4]: "
                          "conv / input-gradient MFMA operands in bf16, fp32 accumulate, fp32 HBM tensors / weight gradients / Adam")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
+                    help="model_config override (JSON value), e.g. --set num_layers=4 --set num_initial_filters=8")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="stop after process-group initialisation + tuning-table broadcast (launcher check; runs without a GPU)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(relaunch_under_torchrun(args.gpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:       # before any rendezvous: a mismatch must not hang
+        raise SystemExit("--gpus %d but WORLD_SIZE=%s" % (args.gpus, os.environ.get("WORLD_SIZE")))
+    if args.dry_run:
+        return dry_run(args)
 
     import wave_u_net_amd as wun
     from wave_u_net_amd import _lib
     from wave_u_net_amd.training import Trainer, synthetic_source
 
-    if args.config == "m1_context" and args.batch == 16 and "WUN_TUNE_CACHE" not in os.environ \
-            and os.path.exists(PINNED_TUNE_TABLE) and os.environ.get("WUN_NO_TUNE") is None:
-        os.environ["WUN_TUNE_CACHE"] = PINNED_TUNE_TABLE      # the tilings the committed profiles describe
+    # the tilings the committed profiles describe: handed to the Trainer as TEXT (read-only; ADVICE round 2 -- the
+    # tracked file must never double as the writable WUN_TUNE_CACHE)
+    pinned_path = PINNED_TUNE_TABLES.get((args.config, args.batch, args.dtype)) if not args.set else None
+    pinned_text = open(pinned_path).read() if (pinned_path and os.path.exists(pinned_path)
+                                               and "WUN_TUNE_CACHE" not in os.environ) else None
 
     if args.force_allreduce and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -206,15 +300,14 @@ def main():
         torch.cuda.set_device(0)
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
 
-    cfg = wun.get_config(args.config)
+    cfg = wun.get_config(args.config, **parse_overrides(args.set))
     if args.dtype == "bf16":
         cfg["compute_dtype"] = "bf16"
-        os.environ.pop("WUN_TUNE_CACHE", None) if os.environ.get("WUN_TUNE_CACHE") == PINNED_TUNE_TABLE else None
     log("building trainer")
     tr = Trainer(cfg, batch_size=args.batch, bucket_mib=args.bucket_mib)
     world = tr.world
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     forced = None
     if args.force_allreduce and world == 1:
         from wave_u_net_amd.parallel import OverlappedGradAllReducer
@@ -240,11 +333,11 @@ def main():
         return loss_
 
     t_tune = time.time()
-    tr.tune(mix, targets)                      # pinned table, or one-off autotuning on rank 0 + broadcast (untimed)
+    tr.tune(mix, targets, pinned_table=pinned_text)   # pinned table, or one-off autotuning on rank 0 + broadcast (untimed)
     table_text = getattr(tr, "tune_table", None)
-    pinned = bool(table_text) and os.path.exists(PINNED_TUNE_TABLE) and table_text == open(PINNED_TUNE_TABLE).read()
-    log("tilings: %s (%.2f s)" % ("pinned table profiles/round2_tune_table.txt" if pinned else
-                                 ("autotuned" if table_text else "heuristic (WUN_NO_TUNE)"), time.time() - t_tune))
+    pinned = tr.tune_source == "pinned"          # decided by whether the import of the committed text SUCCEEDED
+    tilings = ("pinned:" + os.path.relpath(pinned_path, ROOT)) if pinned else tr.tune_source
+    log("tilings: %s (%.2f s)" % (tilings, time.time() - t_tune))
 
     # ---- step 0 of the timed inputs, kept for the parity object (no optimizer step: weights untouched) ----
     gpu0 = None
@@ -262,9 +355,15 @@ def main():
     log("warm-up done")
     barrier()
     torch.cuda.synchronize()
+    # one HIP event per step on the stream the step is launched on (torch's current stream = the stream handed to
+    # the C ABI): per-step durations for the median / p10 / p90 of SURVEY section 8(d); `value` stays the wall clock
+    # of the whole region
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    evs[0].record()
+    for i in range(args.steps):
         loss = step()
+        evs[i + 1].record()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -276,6 +375,7 @@ def main():
     loss_val = float(loss.item())
     log("timed region: %d steps in %.3f s (%.2f ms/step)" % (args.steps, elapsed, 1e3 * elapsed / args.steps))
 
+    step_ms = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)])
     info = tr.sep.plan_info()
     ms_per_step = 1e3 * elapsed / args.steps
     out_samples = world * tr.batch * tr.t_out
@@ -286,6 +386,8 @@ def main():
         "unit": "output samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step,
+        "ms_median": float(np.median(step_ms)), "ms_p10": float(np.percentile(step_ms, 10)),
+        "ms_p90": float(np.percentile(step_ms, 90)),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.dtype == "f32" else "bf16 (conv/dgrad MFMA operands; fp32 accumulate, storage, wgrad, Adam)",
         "data": "synthetic",
@@ -301,7 +403,7 @@ def main():
                    "input_frames": tr.t_in, "output_frames": tr.t_out,
                    "input_samples_per_s": world * tr.batch * tr.t_in * args.steps / elapsed,
                    "parallelism": "dp%d" % world, "final_loss": loss_val,
-                   "tilings": "pinned:profiles/round2_tune_table.txt" if pinned else ("autotuned" if table_text else "heuristic"),
+                   "tilings": tilings,
                    "forced_allreduce": bool(forced), "bucket_mib": args.bucket_mib,
                    "step_tflops_executed": step_flops / 1e12,
                    "step_tflops_reference_graph": 3.0 * info.fwd_flops_dense / 1e12,

@@ -21,12 +21,13 @@
  * state.  wun_profile_begin/end and the wun_op_* entry points (single-operator tests and
  * benchmarks) use process-global state and are not meant for concurrent use.
  *
- * Streams: the side streams are created at the LOWEST queue priority (their work -- weight gradients, deferred
- * skip-window convs -- fills the gaps of the dependent chain on the caller's stream), and the plan's internal
- * cross-stream events carry no system-scope fence: they order kernels of this device only.  Everything a call
- * enqueues is complete with respect to the caller's stream when the call's work on that stream is (the last
- * internal operation of every call is the caller's stream waiting for the side streams); host code synchronises
- * through that stream, never through the plan's events.
+ * Streams: the side streams (weight gradients, deferred skip-window convs: work that fills the gaps of the
+ * dependent chain on the caller's stream) are created at NORMAL queue priority, and at the LOWEST priority only
+ * when wun_config.exclusive_streams = 1 (nothing else shares the device; see the field's comment for the hazard).
+ * The plan's internal cross-stream events carry no system-scope fence: they order kernels of this device only.
+ * Everything a call enqueues is complete with respect to the caller's stream when the call's work on that stream
+ * is (the last internal operation of every call is the caller's stream waiting for the side streams); host code
+ * synchronises through that stream, never through the plan's events.
  *
  * Tensor layouts at the boundary are the reference's: audio is float32 [B, T, C]
  * (channel-last, exactly what get_output receives/returns); kernels are TF layout

@@ -57,9 +57,28 @@ def params_to_torch(params, dtype=torch.float32, requires_grad=False):
 # ---------------------------------------------------------------------------
 # ops (all on NCW tensors [B, C, T]; the public functions take/return [B, T, C])
 # ---------------------------------------------------------------------------
+class _TfLeakyReLU(torch.autograd.Function):
+    """Utils.LeakyReLU, Utils.py:79-80: tf.maximum(alpha * x, x) with alpha = 0.2, INCLUDING TensorFlow's
+    gradient at the tie.  TF-1.8's _MaximumGrad (math_grad.py, _MaximumMinimumGrad) routes the incoming gradient
+    to the FIRST argument where `greater_equal(first, second)` holds and to the second elsewhere; here the first
+    argument is alpha*x, so d/dx = alpha wherever alpha*x >= x, i.e. for x <= 0 -- 0.2 at x == 0 exactly
+    (torch.maximum would split the tie 0.5/0.5 -> 0.6).  Exact zeros are the common case on real stems: digital
+    silence through zero-initialised biases (Datasets.py:188-216 feeds MUSDB vocals)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.maximum(0.2 * x, x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return g * torch.where(0.2 * x >= x, torch.full_like(x, 0.2), torch.ones_like(x))
+
+
 def leaky_relu(x):
-    """Utils.LeakyReLU, Utils.py:79-80: max(0.2*x, x)."""
-    return torch.maximum(0.2 * x, x)
+    """Utils.LeakyReLU, Utils.py:79-80: max(0.2*x, x); gradient 0.2 at x == 0 as in TensorFlow."""
+    return _TfLeakyReLU.apply(x)
 
 
 def conv1d_tf(x, kernel, bias, same):

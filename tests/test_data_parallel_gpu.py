@@ -76,3 +76,23 @@ def test_two_rank_resume_keeps_replicas_identical(tmp_path):
     for k in ("params", "m", "v"):
         assert np.array_equal(a[k], b[k]), k                 # bit-identical replicas (same tilings on both ranks)
     assert str(a["table"]) == str(b["table"]) and str(a["table"]).startswith("wun-tune 2 ")
+
+
+def test_bench_launches_itself_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` with no launcher around it (the driver's command shape): bench.py re-executes itself
+    under torch.distributed.run, both ranks share this box's GPU (exchange over gloo), rank 0 prints ONE JSON line
+    with n_gpus = 2 and the per-step statistics.  Tiny config so the run takes seconds."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(WUN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "full", "--batch", "3",
+           "--set", "num_layers=4", "--set", "num_initial_filters=8", "--set", "num_frames=72",
+           "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 4 and d["config"]["global_batch"] == 6
+    assert d["value"] > 0 and d["ms_p10"] <= d["ms_median"] <= d["ms_p90"]
+    assert np.isfinite(d["config"]["final_loss"])

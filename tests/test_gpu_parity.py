@@ -537,8 +537,8 @@ def test_full_size_named_configs_step_vs_oracle(lib, name):
 def test_deep_variant_16_levels_48_filters(lib):
     """BASELINE.json configs[4] architecture: 16 levels, 48 base channels, stereo, 4 sources,
     same padding, 589824-sample excerpt (9 * 2^16), 92.45 M parameters -- one excerpt, fp32:
-    forward vs the oracle, loss, and a subset of gradient tensors (the oracle's backward of this
-    model takes tens of seconds on the host)."""
+    forward vs the oracle, loss, and EVERY gradient tensor (heuristic tilings; the tuned plan is checked
+    against the float64 oracle by test_deep_variant_tuned_all_gradients_vs_float64)."""
     over = dict(num_layers=16, num_initial_filters=48, mono_downmix=False, task="multi_instrument",
                 output_type="difference")
     ocfg = shapes.finalize_config(dict(shapes.BASE_MODEL_CONFIG, **over))
@@ -562,6 +562,89 @@ def test_deep_variant_16_levels_48_filters(lib):
     _out_check(outs, oouts, ocfg["source_names"], "deep_l16_f48 (fp32 oracle)")
     _loss_check(loss.item(), oloss.item(), "deep_l16_f48 (fp32 oracle)")
     _grad_check(sep, tp, ograds, tol=5e-3, tag="deep_l16_f48 (fp32 oracle)")
+
+
+def test_deep_variant_tuned_all_gradients_vs_float64(lib):
+    """BASELINE.json configs[4] architecture (16 levels, 48 base channels, stereo, 4 sources, same padding) with the
+    AUTOTUNED plan (wun_plan_tune -- the tilings the deep figures of DESIGN.md section 6 run), every one of its
+    gradient tensors against the FLOAT64 oracle at the normal gradient tolerance.  The excerpt is 2 * 2^16 samples
+    instead of 9 * 2^16 so that the float64 autograd graph stays within a few GB of host memory (same-padding
+    model: every level, tile shape family and split-K path of the full-size plan is exercised; only the number of
+    time tiles per launch differs), batch 2, oracle one excerpt at a time."""
+    over = dict(num_layers=16, num_initial_filters=48, mono_downmix=False, task="multi_instrument",
+                output_type="difference")
+    ocfg = shapes.finalize_config(dict(shapes.BASE_MODEL_CONFIG, **over))
+    params = golden_params(ocfg, 95)
+    sep = UnetAudioSeparator(wun.get_config("baseline", **over), device="cuda:0")
+    B, T = 2, 2 * 65536
+    mix, targets = wt.synthetic_batch(ocfg, B, T, T, seed=96)
+    sep._plan(B, T); sep._active = sep._plans[(B, T)]
+    sep.load_variables(params)
+    dmix = torch.from_numpy(mix).cuda()
+    tg = {k: torch.from_numpy(v) for k, v in targets.items()}
+    sep.tune(dmix, tg)
+    assert sep.tune_export().startswith("wun-tune 2 ")
+    outs = sep.get_output(dmix, True)
+    loss = sep.loss_and_gradients(tg)
+    torch.cuda.synchronize()
+    oloss, ograds, oouts, tp = _oracle64(ocfg, params, mix, targets)
+    assert len(tp) == len(ograds) == len(sep._active.tensors)
+    _out_check(outs, oouts, ocfg["source_names"], "deep_l16_f48 tuned (float64 oracle)")
+    _loss_check(loss.item(), oloss, "deep_l16_f48 tuned (float64 oracle)")
+    _grad_check(sep, tp, ograds, tag="deep_l16_f48 tuned (float64 oracle)")
+
+
+@pytest.mark.parametrize("name", ["baseline_context_small", "full_small", "baseline_small"])
+def test_leaky_relu_tie_digital_silence(lib, name):
+    """LeakyReLU at exactly 0 (Utils.py:79-80, tf.maximum(0.2x, x): TensorFlow's _MaximumGrad gives the tie to the
+    first argument => gradient 0.2).  Digitally silent input segments with zero biases make exact-zero
+    pre-activations the COMMON case at step 0 on real stems (Datasets.py:188-216 feeds MUSDB vocals): excerpt 0 is
+    entirely silent, excerpt 1 is silent in its first half -- with zero biases every conv output over a silent
+    stretch is exactly 0.0, so the tie rule decides the weight gradients of every layer above.  Outputs, loss and
+    all gradients vs the float64 oracle (whose LeakyReLU implements the TF rule); a tie handled the torch way
+    (0.6) or the 'natural' way (1.0) fails this test by orders of magnitude."""
+    case = GOLDEN_CASES[name]
+    ocfg = _ocfg(case)
+    params = [(n, (np.zeros_like(v) if n.endswith("/bias") else v)) for n, v in golden_params(ocfg, case["seed"])]
+    sep, cfg = _make_sep(case, params)
+    B = 3
+    i, o = shapes.get_padding(ocfg, [B, case["frames"], 0])
+    mix, targets = wt.synthetic_batch(ocfg, B, i[1], o[1], seed=case["seed"] + 300)
+    mix = mix.copy(); targets = {k: v.copy() for k, v in targets.items()}
+    pad = (i[1] - o[1]) // 2
+    mix[0] = 0.0
+    mix[1, :i[1] // 2] = 0.0
+    for k in targets:                                    # the sources of a silent mix are silent (Utils.py:35)
+        targets[k][0] = 0.0
+        targets[k][1, :max(0, i[1] // 2 - pad)] = 0.0
+    sep._plan(B, i[1]); sep._active = sep._plans[(B, i[1])]
+    sep.load_variables(params)
+    outs = sep.get_output(torch.from_numpy(mix).cuda(), True)
+    loss = sep.loss_and_gradients({k: torch.from_numpy(v) for k, v in targets.items()})
+    torch.cuda.synchronize()
+    tp = wt.params_to_torch(params, torch.float64, requires_grad=True)
+    tmix = torch.tensor(mix, dtype=torch.float64)
+    ttg = {k: torch.tensor(v, dtype=torch.float64) for k, v in targets.items()}
+    oloss, ograds = wt.train_step(ocfg, tp, tmix, ttg)
+    oouts = wt.get_output(ocfg, tp, tmix, True)
+    # the construction really produces ties: the first conv's pre-activation of the silent excerpt is exactly 0
+    k0, b0 = tp[0][1].detach(), tp[1][1].detach()
+    pre = wt.conv1d_tf(tmix[:1].permute(0, 2, 1), k0, b0, not ocfg["context"])
+    assert (pre == 0).all()
+    _out_check(outs, oouts, ocfg["source_names"], "lrelu_tie_" + name)
+    _loss_check(loss.item(), oloss.item(), "lrelu_tie_" + name)
+    _grad_check(sep, tp, ograds, tag="lrelu_tie_" + name)
+    # sensitivity of the construction: with the tie split the torch way the oracle itself moves by far more than
+    # the tolerance, i.e. this test can tell the rules apart
+    tp2 = wt.params_to_torch(params, torch.float64, requires_grad=True)
+    old = wt.leaky_relu
+    try:
+        wt.leaky_relu = lambda x: torch.maximum(0.2 * x, x)
+        _, g_split = wt.train_step(ocfg, tp2, tmix, ttg)
+    finally:
+        wt.leaky_relu = old
+    moved = max(((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item() for a, b in zip(g_split, ograds))
+    assert moved > 20 * GRAD_TOL, moved          # observed 0.05 .. 0.10 of max|g| vs GRAD_TOL 5e-4
 
 
 @pytest.mark.parametrize("name", ["full_multi_small", "baseline_small"])
@@ -615,26 +698,22 @@ def test_autotuned_full_size_m1_context(lib):
 def test_benchmarked_configuration_b16_tuned_vs_oracle(lib):
     """EXACTLY what bench.py times -- BASELINE.json configs[1]: M1 with context, batch 16,
     147443 -> 16389 samples, the Trainer's seed-1337 weights, the synthetic_source(seed 1337) batch
-    and the tilings bench.py runs (the pinned table profiles/round2_tune_table.txt through
-    WUN_TUNE_CACHE when it matches this build, a fresh wun_plan_tune otherwise) -- compared element
+    and the tilings bench.py runs (the committed table profiles/round2_tune_table.txt, handed to
+    Trainer.tune as read-only text, when it matches this build; a fresh wun_plan_tune otherwise) -- compared element
     by element with the FLOAT64 oracle: outputs, loss and all 54 gradient tensors of the whole batch
     (the oracle runs one excerpt at a time and averages: the loss is a mean over excerpts)."""
     from wave_u_net_amd.training import Trainer, synthetic_source
     cfg = wun.get_config("m1_context")
     table = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "round2_tune_table.txt")
-    old = os.environ.get("WUN_TUNE_CACHE")
-    if os.path.exists(table):
-        os.environ["WUN_TUNE_CACHE"] = table
-    try:
-        tr = Trainer(cfg, batch_size=16)
-        assert (tr.t_in, tr.t_out) == (147443, 16389)
-        mix, targets = synthetic_source(cfg, 16, tr.t_in, tr.t_out, tr.device, seed=1337)()
-        tr.tune(mix, targets)
-    finally:
-        if old is None:
-            os.environ.pop("WUN_TUNE_CACHE", None)
-        else:
-            os.environ["WUN_TUNE_CACHE"] = old
+    text = open(table).read() if os.path.exists(table) else None
+    before = text
+    tr = Trainer(cfg, batch_size=16)
+    assert (tr.t_in, tr.t_out) == (147443, 16389)
+    mix, targets = synthetic_source(cfg, 16, tr.t_in, tr.t_out, tr.device, seed=1337)()
+    tr.tune(mix, targets, pinned_table=text)          # the committed table is handed over as text: read-only
+    assert tr.tune_source in ("pinned", "cache", "autotuned")
+    if text is not None:
+        assert open(table).read() == before           # never rewritten (ADVICE round 2)
     sep = tr.sep
     assert sep.tune_export().startswith("wun-tune 2 ")               # the plan really runs tuned tilings
     outs = sep.get_output(mix, True)

@@ -67,6 +67,12 @@ _SIGS = {
 EXPORTED_SYMBOLS = tuple(sorted(_SIGS))
 _lib = None
 
+# Process-wide record of the scheduling hint wun_config.exclusive_streams (include/wun.h): plans created with it run
+# their side streams on LOWEST-priority hardware queues, and a process that has ever created those queues is ~40 %
+# slower once a communication stream (RCCL) shares the device.  parallel.init_distributed() refuses to start a
+# process group after such a plan exists (the hazard cannot be undone inside the process).
+LOW_PRIORITY_PLANS = {"created": 0}
+
 
 def load():
     """Load libwun.so.  torch must already be imported on a GPU box so that the library

@@ -153,6 +153,20 @@ __device__ __forceinline__ int xcd_contiguous_block(int bid, int grid) {
 
 #define WUN_JMAX 15
 
+#ifdef WUN_ABLATION
+// Workgroup life-cycle trace of the conv kernel (diagnostic builds only; WUN_ABLATE bit 64): per workgroup
+// {entry, first chunk staged, chunk loop done, end} shader-clock stamps, HW_ID / XCC_ID and the constant 100 MHz
+// clock at entry / end (effective shader clock = d(stamp) / d(realtime)).
+#define WUN_TRACE_WGS 16384
+__device__ int g_wun_knob[4];      // [0] first-round stagger in shader cycles per co-resident index, [1] staging priority
+__device__ unsigned long long g_wun_trace[WUN_TRACE_WGS * 16];
+#define WUN_TRACE_STAMP(i) do { if (tr_on) trp[i] = __builtin_readcyclecounter(); } while (0)
+#define WUN_TRACE_END() do { if (tr_on) { trp[3] = __builtin_readcyclecounter(); trp[6] = wall_clock64(); } } while (0)
+#else
+#define WUN_TRACE_STAMP(i) do { } while (0)
+#define WUN_TRACE_END() do { } while (0)
+#endif
+
 // floor(n / d) for 0 <= n < 2^22, d >= 1 with inv = 1.0f / d: one multiply + a +/-1 fix-up instead of the ~35
 // instruction integer division (the batch-folded tiles of the deep, launch-latency-bound levels do a dozen of
 // these per thread before their first load)
@@ -198,6 +212,36 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
     const int lane = tid & 63;
     const int li = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef WUN_ABLATION
+    const bool tr_on = (a.flags & 16384) && tid == 0 && blockIdx.x < WUN_TRACE_WGS;
+    unsigned long long* trp = g_wun_trace + (size_t)(blockIdx.x < WUN_TRACE_WGS ? blockIdx.x : 0) * 16;
+    if (tr_on) {
+        trp[0] = __builtin_readcyclecounter();
+        trp[5] = wall_clock64();
+        trp[4] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                 ((unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15) << 32);
+    }
+#endif
+#ifdef WUN_ABLATION
+    {
+        const int lagc = g_wun_knob[0];
+        if (lagc > 0 && blockIdx.x < 1024 && blockIdx.x >= 256) {
+            const long long until = (long long)__builtin_readcyclecounter() + (long long)(blockIdx.x >> 8) * lagc;
+            while ((long long)__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(64);
+        }
+    }
+    const int stprio = g_wun_knob[1];
+#define WUN_PRIO_HI() do { if (stprio) __builtin_amdgcn_s_setprio(2); } while (0)
+#define WUN_PRIO_LO() do { if (stprio) __builtin_amdgcn_s_setprio(0); } while (0)
+    WUN_PRIO_HI();
+#elif defined(WUN_STAGE_PRIO)
+#define WUN_PRIO_HI() __builtin_amdgcn_s_setprio(2)
+#define WUN_PRIO_LO() __builtin_amdgcn_s_setprio(0)
+    WUN_PRIO_HI();
+#else
+#define WUN_PRIO_HI() do { } while (0)
+#define WUN_PRIO_LO() do { } while (0)
+#endif
     int bid = xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x);
     const int nt = bid % nNT; bid /= nNT;
     const int tt = bid % nTT; bid /= nTT;
@@ -226,8 +270,17 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
     int ch_hi = ch_lo + a.cps;
     if (ch_hi > nchunks) ch_hi = nchunks;
 
-    const float* src0b = a.src0 + (long long)b * a.bs0 + a.off0;
-    const float* src1b = (a.src1 != nullptr) ? a.src1 + (long long)b * a.bs1 + a.off1 : src0b;
+#ifdef WUN_ABLATION
+    const bool ab_hot = (a.flags & 32768) != 0;
+    const int b_ld = ab_hot ? 0 : b, q0_ld = ab_hot ? 0 : q0;
+    const bool ab_hotst = (a.flags & 65536) != 0;
+    const int b_st = ab_hotst ? 0 : b, q0_st = ab_hotst ? 0 : q0;
+#else
+    const int b_ld = b, q0_ld = q0;
+    const int b_st = b, q0_st = q0;
+#endif
+    const float* src0b = a.src0 + (long long)b_ld * a.bs0 + a.off0;
+    const float* src1b = (a.src1 != nullptr) ? a.src1 + (long long)b_ld * a.bs1 + a.off1 : src0b;
 
     f32x4 acc[MT][NW];
 #pragma unroll
@@ -249,7 +302,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
         const int lr = deint ? tid % TPC : tid % TPR;
         const int stride_i = deint ? TPC : TPR;
         const int lim = deint ? 2 * UW : UW;
-        const int tbase = (deint ? 2 * q0 : q0) - a.shift;
+        const int tbase = (deint ? 2 * q0_ld : q0_ld) - a.shift;
         const int seglen = deint ? 2 * fold_seg : fold_seg;
         const float inv_seglen = 1.0f / (float)seglen;
 #pragma unroll
@@ -480,9 +533,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
     // Pipeline: global loads of chunk c+1 are issued before the MFMAs of chunk c; their LDS
     // writes (to the other buffer) sit in the middle of chunk c's MFMA loop, so they issue in
     // the shadow of the matrix pipe; one barrier per chunk.
+    WUN_TRACE_STAMP(7);
     if (ch_lo < ch_hi && !ab_noload) load_chunk(ch_lo);
+    WUN_TRACE_STAMP(8);
     if (ch_lo < ch_hi && !ab_nostore) store_chunk(0);
+    WUN_TRACE_STAMP(9);
     __syncthreads();
+    WUN_TRACE_STAMP(1);
+    WUN_PRIO_LO();
 #ifndef WUN_STORE_AT
 #define WUN_STORE_AT 2   /* numerator of the tap-loop fraction (over 4) after which the next chunk is written to LDS */
 #endif
@@ -490,12 +548,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
     for (int chunk = ch_lo; chunk < ch_hi; ++chunk) {
         const int cur = ((chunk - ch_lo) & 1) * LB;
         const bool has_next = chunk + 1 < ch_hi;
+        WUN_PRIO_HI();
         if (has_next && !ab_noload) load_chunk(chunk + 1);
+        WUN_PRIO_LO();
         if (!ab_nomfma) run_taps(cur, 0, half);
+        WUN_PRIO_HI();
         if (has_next && !ab_nostore) store_chunk(LB - cur);
+        WUN_PRIO_LO();
         if (!ab_nomfma) run_taps(cur, half, J);
         if (!ab_nobar) __syncthreads();
     }
+    WUN_TRACE_STAMP(2);
+    WUN_PRIO_HI();
 
     // ---- split-K: raw partial tile, epilogue runs in conv_splitk_epilogue_kernel ----
     if (a.part != nullptr) {
@@ -520,6 +584,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
                 }
             }
         }
+        WUN_TRACE_END();
         return;
     }
 
@@ -534,10 +599,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
             for (int n = 0; n < NW / 2; ++n) {
                 const int ncol = n0h + n * 16 + li;
                 if (ncol >= a.N) continue;
-                const long long rowbase = (long long)b * a.obs0 + (long long)ncol * a.opitch0 + a.ooff0;
+                const long long rowbase = (long long)b_st * a.obs0 + (long long)ncol * a.opitch0 + a.ooff0;
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    const int q = q0 + wt0 + m * 16 + lg * 4;
+                    const int q = q0_st + wt0 + m * 16 + lg * 4;
                     const int t0 = 2 * q;
                     float v[8];
 #pragma unroll
@@ -576,6 +641,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
                 }
             }
         }
+        WUN_TRACE_END();
         return;
     }
 
@@ -591,17 +657,17 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
         const float bvv = (a.bias != nullptr) ? a.bias[ncol] : 0.f;
         float* dst; const float* msk; long long rowbase;
         if (ncol < a.N0) {
-            rowbase = (long long)b * a.obs0 + (long long)ncol * a.opitch0 + a.ooff0;
+            rowbase = (long long)b_st * a.obs0 + (long long)ncol * a.opitch0 + a.ooff0;
             dst = a.dst0; msk = a.msk0;
         } else {
-            rowbase = (long long)b * a.obs1 + (long long)(ncol - a.N0) * a.opitch1 + a.ooff1;
+            rowbase = (long long)b_st * a.obs1 + (long long)(ncol - a.N0) * a.opitch1 + a.ooff1;
             dst = a.dst1; msk = a.msk1;
         }
         float* decrow = (a.dec != nullptr && ncol < a.N0)
                             ? a.dec + (long long)b * a.decbs + (long long)ncol * a.decpitch : nullptr;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const int q = q0 + wt0 + m * 16 + lg * 4;
+            const int q = q0_st + wt0 + m * 16 + lg * 4;
             if constexpr (FOLD) {
                 int g = fast_div(q, a.Tout, inv_tout), qq = q - g * a.Tout;
                 const bool first = ncol < a.N0;
@@ -661,6 +727,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
             }
         }
     }
+    WUN_TRACE_END();
 }
 
 // sums the split-K partial tiles in a fixed order and applies the conv epilogue.  One thread = 4
@@ -2145,3 +2212,24 @@ hipError_t launch_head_bwd_off(const HeadArgs& a, const long long* hoff, hipStre
 }
 
 }  // namespace wun
+
+#ifdef WUN_ABLATION
+// diagnostic builds only: copy / clear the conv kernel's workgroup trace (WUN_ABLATE bit 64)
+extern "C" int wun_dbg_set_knob(int idx, int value) {
+    if (idx < 0 || idx >= 4) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(wun::g_wun_knob), &value, sizeof(int), idx * sizeof(int)) == hipSuccess ? 0 : -2;
+}
+extern "C" int wun_dbg_trace_read(unsigned long long* host, int nwg, int clear) {
+    if (nwg > WUN_TRACE_WGS) nwg = WUN_TRACE_WGS;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (host != nullptr &&
+        hipMemcpyFromSymbol(host, HIP_SYMBOL(wun::g_wun_trace), (size_t)nwg * 16 * sizeof(unsigned long long)) != hipSuccess)
+        return -2;
+    if (clear) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(wun::g_wun_trace)) != hipSuccess) return -3;
+        if (hipMemset(p, 0, sizeof(unsigned long long) * WUN_TRACE_WGS * 16) != hipSuccess) return -4;
+    }
+    return nwg;
+}
+#endif

@@ -23,6 +23,14 @@ def init_distributed(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
+        from . import _lib
+        if _lib.LOW_PRIORITY_PLANS["created"] and os.environ.get("WUN_ALLOW_LOW_PRIO_WITH_COLLECTIVES") is None:
+            # include/wun.h, wun_config.exclusive_streams: the lowest-priority hardware queues of an earlier
+            # single-GPU plan stay with the process and cost the data-parallel step ~40 %
+            raise RuntimeError(
+                "a plan with exclusive_streams=1 (lowest-priority side streams) was created in this process before the "
+                "process group: initialise torch.distributed first, or build that separator with "
+                "model_config['exclusive_streams'] = False (override: WUN_ALLOW_LOW_PRIO_WITH_COLLECTIVES=1)")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

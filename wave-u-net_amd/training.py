@@ -73,40 +73,50 @@ class Trainer(object):
             self.reducer = GradAllReducer(plan.tensors, plan.info.arena_floats, bucket_mib)
         self.lr = model_config["init_sup_sep_lr"]
 
-    def tune(self, mix, targets):
+    def tune(self, mix, targets, pinned_table=None):
         """One-off kernel autotuning on a real batch (skipped with WUN_NO_TUNE=1).  Rank 0 decides
-        the tilings -- from WUN_TUNE_CACHE=<file> if it holds a table for this plan and library
-        build, else by measuring (wun_plan_tune) -- and broadcasts the exported table; every rank
-        imports that same table, so all replicas run bit-identical kernels (per-rank tuning would
-        let replicas differ by fp32 rounding before the gradient all-reduce) and nobody reads a
-        cache file that another rank is still writing.  The cache is written atomically."""
+        the tilings -- from `pinned_table` (the TEXT of a committed table: read-only, never written
+        back), else from WUN_TUNE_CACHE=<file> (a writable cache) if either holds a table for this
+        plan and library build, else by measuring (wun_plan_tune) -- and broadcasts the exported
+        table; every rank imports that same table, so all replicas run bit-identical kernels
+        (per-rank tuning would let replicas differ by fp32 rounding before the gradient all-reduce)
+        and nobody reads a cache file that another rank is still writing.  The cache is written
+        atomically.  `tune_source` records which of "pinned" / "cache" / "autotuned" / "heuristic"
+        happened (decided by whether the import SUCCEEDED, not by comparing files afterwards)."""
+        self.tune_source, self.tune_table = "heuristic", None
         if os.environ.get("WUN_NO_TUNE") is not None:
             return
         cache = os.environ.get("WUN_TUNE_CACHE")
         self.sep.get_output(mix, True)                    # makes this (batch, length) plan the active one
-        table = None
+        table, source = None, None
         if self.rank == 0:
-            if cache and os.path.exists(cache):
+            if pinned_table:
+                try:
+                    self.sep.tune_import(pinned_table)
+                    table, source = pinned_table, "pinned"
+                except ValueError:
+                    table = None                         # other plan / library build: fall through
+            if table is None and cache and os.path.exists(cache):
                 try:
                     text = open(cache).read()
                     self.sep.tune_import(text)
-                    table = text
+                    table, source = text, "cache"
                 except ValueError:
                     table = None                         # other plan / library build / truncated: tune afresh
             if table is None:
                 self.sep.tune(mix, targets)
-                table = self.sep.tune_export()
+                table, source = self.sep.tune_export(), "autotuned"
                 if cache:
                     tmp = "%s.tmp.%d" % (cache, os.getpid())
                     with open(tmp, "w") as f:
                         f.write(table)
                     os.replace(tmp, cache)
+        box = [table, source]
         if self.world > 1:
-            box = [table]
             dist.broadcast_object_list(box, src=0)
             if self.rank != 0:
                 self.sep.tune_import(box[0])
-        self.tune_table = table if self.rank == 0 else box[0]
+        self.tune_table, self.tune_source = box[0], box[1]
 
     def step(self, mix, targets):
         self.sep.get_output(mix, True)
