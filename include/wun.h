@@ -254,6 +254,12 @@ int wun_profile_end(char* json_out, int64_t capacity);
 const char* wun_last_error(void);
 const char* wun_version(void);
 
+/* sizeof() of the structs this header declares, as the LIBRARY was compiled: sizes[0] = wun_config,
+ * sizes[1] = wun_plan_info, sizes[2] = wun_tensor_info; writes min(n, 3) entries and returns 3.  A binding written
+ * in another language (the ctypes stub of INTEGRATION.md, cffi, cgo ...) checks its own struct sizes against these
+ * before the first call instead of passing a short struct to a library that reads a longer one. */
+int wun_abi_sizes(int64_t* sizes, int n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -148,3 +148,37 @@ def test_scheduling_hint_defaults_to_shared_device():
     body = hdr[hdr.index("typedef struct wun_config"):hdr.index("} wun_config;")]
     names = [ln.split(";")[0].split()[-1] for ln in body.splitlines() if ln.strip().startswith("int32_t")]
     assert names == [n for n, _ in c0._fields_]
+
+
+def test_integration_doc_stub_matches_the_binding(lib):
+    """INTEGRATION.md's ctypes stub is what a maintainer pastes: its field list must be the binding's, and the struct it
+    builds must have the size the library was compiled with (round 2: the stub had 13 of 14 fields)."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blk = doc[doc.index("class WunConfig(C.Structure):"):]
+    blk = blk[:blk.index(")]") + 2]
+    fields = re.findall(r'"([a-z_]+)"', blk)
+    assert fields == [n for n, _ in _lib.WunConfig._fields_]
+    sizes = (C.c_int64 * 3)()
+    assert lib.wun_abi_sizes(sizes, 3) == 3
+    assert sizes[0] == 4 * len(fields) == C.sizeof(_lib.WunConfig)
+    assert sizes[1] == C.sizeof(_lib.WunPlanInfo) and sizes[2] == C.sizeof(_lib.WunTensorInfo)
+    init = re.search(r"cfg = WunConfig\(([^)]*)\)", doc).group(1)
+    assert len(init.split(",")) == len(fields)
+
+
+def test_c_caller_links_and_runs(tmp_path):
+    """tests/abi_smoke.c: a plain C program against include/wun.h + libwun.so (no ctypes, no torch)."""
+    import shutil
+    import subprocess
+    cc = shutil.which("gcc") or shutil.which("cc")
+    assert cc, "no C compiler"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = os.path.join(str(tmp_path), "abi_smoke")
+    cmd = [cc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "abi_smoke.c"),
+           "-L", libdir, "-lwun", "-L", "/opt/rocm/lib", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib",
+           "-Wl,--allow-shlib-undefined", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "abi_smoke: ok" in r.stdout

@@ -60,6 +60,7 @@ _SIGS = {
     "wun_op_conv1d_ex": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, _P, _P] + [C.c_int] * 12 + [_P]),
     "wun_profile_begin": (C.c_int, []),
     "wun_profile_end": (C.c_int, [C.c_char_p, C.c_int64]),
+    "wun_abi_sizes": (C.c_int, [C.POINTER(C.c_int64), C.c_int]),
     "wun_last_error": (C.c_char_p, []),
     "wun_version": (C.c_char_p, []),
 }
@@ -89,6 +90,12 @@ def load():
         fn = getattr(lib, name)      # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
+    # the structs of this binding against the sizes the library was compiled with (wun_abi_sizes, include/wun.h)
+    sizes = (C.c_int64 * 3)()
+    lib.wun_abi_sizes(sizes, 3)
+    mine = (C.sizeof(WunConfig), C.sizeof(WunPlanInfo), C.sizeof(WunTensorInfo))
+    if tuple(sizes) != mine:
+        raise RuntimeError("libwun.so struct sizes %s != this binding's %s (stale library or binding)" % (tuple(sizes), mine))
     _lib = lib
     return lib
 

@@ -1666,5 +1666,11 @@ extern "C" int wun_profile_end(char* json_out, int64_t capacity) {
     return WUN_OK;
 }
 
+extern "C" int wun_abi_sizes(int64_t* sizes, int n) {
+    const int64_t v[3] = {(int64_t)sizeof(wun_config), (int64_t)sizeof(wun_plan_info), (int64_t)sizeof(wun_tensor_info)};
+    for (int i = 0; i < 3 && i < n && sizes != nullptr; ++i) sizes[i] = v[i];
+    return 3;
+}
+
 extern "C" const char* wun_last_error(void) { return g_err.c_str(); }
 extern "C" const char* wun_version(void) { return "wun 0.2 (gfx950, fp32 MFMA 16x16x4 + bf16 MFMA 16x16x32 speed mode)"; }
