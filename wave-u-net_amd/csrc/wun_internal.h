@@ -52,7 +52,13 @@ struct ConvArgs {
     int cps;         // split-K: channel chunks per split (set by the launcher)
     float* part;     // split-K partial buffer (set by the launcher) or null
     int wb_c8p, wb_npad;   // bf16 mode: W points at the packed image [KW][wb_c8p][wb_npad][8] (wun_bf16.hip)
+    // F_ACCUM applies to the row positions pos = ooff + q*ostride with acc_lo <= pos < acc_lo + acc_len only; elsewhere
+    // the result is stored.  (A down level's input gradient = transposed stride-2 conv over the whole row + the
+    // skip-window conv over the crop window: the window part is computed EARLY on a side stream, the row-wide part
+    // adds it inside the window.)  acc_len == 0 is normalised by launch_conv to "the whole row".
+    int acc_lo; unsigned acc_len;
 };
+__host__ __device__ static inline bool conv_acc_at(const ConvArgs& a, int pos) { return (unsigned)(pos - a.acc_lo) < a.acc_len; }
 
 // Weight/bias gradient launch:  P[split][ (k*C + c)*N + n ] and bias row P[split][KW*C*N + n]
 //   = sum over this split's (b, q-tile) units of in[b][c][q*SI + k - shift] * dz[b][n][q]

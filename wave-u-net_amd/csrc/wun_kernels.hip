@@ -158,7 +158,7 @@ __device__ __forceinline__ int xcd_contiguous_block(int bid, int grid) {
 // {entry, first chunk staged, chunk loop done, end} shader-clock stamps, HW_ID / XCC_ID and the constant 100 MHz
 // clock at entry / end (effective shader clock = d(stamp) / d(realtime)).
 #define WUN_TRACE_WGS 16384
-__device__ int g_wun_knob[4];      // [0] first-round stagger in shader cycles per co-resident index, [1] staging priority
+__device__ int g_wun_knob[4];      // [0] first-round stagger (cycles per co-resident index), [1] staging priority, [2],[3] trace only launches with (Cin, N)
 __device__ unsigned long long g_wun_trace[WUN_TRACE_WGS * 16];
 #define WUN_TRACE_STAMP(i) do { if (tr_on) trp[i] = __builtin_readcyclecounter(); } while (0)
 #define WUN_TRACE_END() do { if (tr_on) { trp[3] = __builtin_readcyclecounter(); trp[6] = wall_clock64(); } } while (0)
@@ -186,7 +186,12 @@ __device__ __forceinline__ int fast_div(int n, int d, float inv) {
 // offsets and the epilogue's (excerpt, position) decode differ from the plain kernel.
 #define WUN_FOLD_XCAP(TT) (3 * (TT) + 32)      // LDS input-row capacity of a FOLD tile (floats per plane)
 
-template <int MT, int NW, int WT, int WN, int CK, bool VECW, bool FOLD = false>
+// XVEC: the input window is staged with 16-byte global loads / wide LDS stores (rows of the plan's buffers are
+// 16-byte aligned): the window starts at the aligned element below its first sample and the sub-vector shift
+// (launch-constant per source: (off - shift) mod 4) is folded into the A-operand LDS offset; the stride-2 loader
+// splits every vector into its two even / two odd samples (two 8-byte stores).  A quarter of the load, store
+// and mask instructions of the element-wise path, which stays for FOLD tiles and unaligned test tensors.
+template <int MT, int NW, int WT, int WN, int CK, bool VECW, bool FOLD = false, bool XVEC = false>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int nNT, int J,
                                                         int XP, int WP) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -200,8 +205,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
     constexpr int TPC = 256 / CH;                                   // DEINT: threads per channel
     constexpr int XIT_I = FOLD ? (2 * WUN_FOLD_XCAP(TT) + TPC - 1) / TPC
                                : (2 * (TT + (WUN_JMAX + 1) / 2 - 1) + TPC - 1) / TPC;
-    constexpr int XIT = XIT_D > XIT_I ? XIT_D : XIT_I;
+    constexpr int XIT = XVEC ? 1 : (XIT_D > XIT_I ? XIT_D : XIT_I);
     constexpr int WIT = (WUN_JMAX * CK * NT4 + 255) / 256;
+    // XVEC: 16-byte vectors per LDS row (upper bounds for J <= WUN_JMAX and any sub-vector shift) and per thread
+    constexpr int NVR_D = (TT + WUN_JMAX - 1 + 3 + 3) / 4;
+    constexpr int NVR_I = (2 * (TT + (WUN_JMAX + 1) / 2 - 1) + 3 + 3) / 4;
+    constexpr int XVIT_D = (CK * NVR_D + 255) / 256, XVIT_I = (CH * NVR_I + 255) / 256;
+    constexpr int XVIT = XVEC ? (XVIT_D > XVIT_I ? XVIT_D : XVIT_I) : 1;
+    static_assert(!(XVEC && FOLD), "vector staging is not implemented for batch-folded tiles");
 
     // two LDS buffers {input window, weight slab}: chunk c+1 is written while chunk c is read
     const int XB = CK * XP, LB = CK * XP + J * CK * WP;      // floats per X tile / per buffer
@@ -213,7 +224,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
     const int li = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef WUN_ABLATION
-    const bool tr_on = (a.flags & 16384) && tid == 0 && blockIdx.x < WUN_TRACE_WGS;
+    const bool tr_on = (a.flags & 16384) && tid == 0 && blockIdx.x < WUN_TRACE_WGS &&
+                       (g_wun_knob[2] == 0 || (g_wun_knob[2] == a.C0 + a.C1 && g_wun_knob[3] == a.N));   // optional launch filter
     unsigned long long* trp = g_wun_trace + (size_t)(blockIdx.x < WUN_TRACE_WGS ? blockIdx.x : 0) * 16;
     if (tr_on) {
         trp[0] = __builtin_readcyclecounter();
@@ -298,7 +310,34 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
     int xt[XIT];
     unsigned xmask_s = 0, wmask_s = 0;
     const int xrow = deint ? tid / TPC : tid / TPR;       // LDS row (DIRECT) / channel (DEINT) staged by this thread
-    {
+    // XVEC state: sub-vector shift of each source, aligned element index of the window start in a source row,
+    // vectors per LDS row, and per staged vector ONE packed register: bit 31 = live | row << 20 | 4 * vector index
+    const int dl0 = XVEC ? (((a.off0 - a.shift) % 4) + 4) % 4 : 0;
+    const int dl1 = (XVEC && a.C1 > 0) ? (((a.off1 - a.shift) % 4) + 4) % 4 : dl0;
+    f32x4 xv[XVIT];
+    int xvo[XVIT];
+    int nvr = 1, e00 = 0, e01 = 0;
+    bool xedge = false;
+    const float* vb0 = a.src0 + (long long)b_ld * a.bs0;                 // row bases WITHOUT the crop offset (aligned)
+    const float* vb1 = (a.src1 != nullptr) ? a.src1 + (long long)b_ld * a.bs1 : vb0;
+    if constexpr (XVEC) {
+        const int tbase = (deint ? 2 * q0_ld : q0_ld) - a.shift;
+        const int span = deint ? 2 * UW : UW;
+        nvr = (span + (dl0 > dl1 ? dl0 : dl1) + 3) >> 2;
+        e00 = a.off0 + tbase - dl0;
+        e01 = a.off1 + tbase - dl1;
+        const int tf0 = tbase - dl0, tf1 = tbase - dl1;                  // time of the first staged element
+        xedge = tf0 < 0 || tf0 + 4 * nvr > a.Tin || (a.C1 > 0 && (tf1 < 0 || tf1 + 4 * nvr > a.Tin));
+        const int rows = deint ? CH : CK;
+        const float inv_nvr = 1.0f / (float)nvr;
+#pragma unroll
+        for (int i = 0; i < XVIT; ++i) {
+            const int f = tid + i * 256;
+            const int row = fast_div(f, nvr, inv_nvr), v = f - row * nvr;
+            xvo[i] = (row < rows) ? (int)(0x80000000u | ((unsigned)row << 20) | (unsigned)(v * 4)) : (int)((unsigned)(v * 4));
+        }
+    }
+    if constexpr (!XVEC) {
         const int lr = deint ? tid % TPC : tid % TPR;
         const int stride_i = deint ? TPC : TPR;
         const int lim = deint ? 2 * UW : UW;
@@ -355,7 +394,23 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
     // waits for the loads and they stay in flight during the MFMAs of the previous chunk ----
     auto load_chunk = [&](int chunk) {
         const int c0 = chunk * CKC;
-        {
+        if constexpr (XVEC) {
+            const int nxv = (deint ? CH : CK) * nvr;
+#pragma unroll
+            for (int i = 0; i < XVIT; ++i) {
+                if (i * 256 < nxv) {                       // uniform
+                    const int pk = xvo[i];
+                    int c = c0 + ((pk >> 20) & 0x7FF);
+                    c = c < Ctot ? c : Ctot - 1;           // rows past the tensor: any valid row (zeroed at the store)
+                    const bool s1 = c >= a.C0;
+                    const float* rp = s1 ? vb1 + (long long)(c - a.C0) * a.pitch1 : vb0 + (long long)c * a.pitch0;
+                    int e = (s1 ? e01 : e00) + (pk & 0xFFFFF);
+                    const int emax = (s1 ? a.pitch1 : a.pitch0) - 4;
+                    e = e < 0 ? 0 : (e > emax ? emax : e);
+                    xv[i] = *reinterpret_cast<const f32x4*>(rp + e);
+                }
+            }
+        } else {
             const int c = c0 + xrow;
             const bool cok = c < Ctot;
             const float* p = (!cok || c < a.C0) ? src0b + (long long)(cok ? c : 0) * a.pitch0
@@ -394,8 +449,40 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
         }
     };
     // ---- registers -> LDS (zero fill applied here) ----
-    auto store_chunk = [&](int bufoff) {
-        if (!deint) {
+    auto store_chunk = [&](int bufoff, int chunk) {
+        if constexpr (XVEC) {
+            const int c0 = chunk * CKC;
+            const bool ctail = c0 + CKC > Ctot;              // uniform
+            const int nxv = (deint ? CH : CK) * nvr;
+#pragma unroll
+            for (int i = 0; i < XVIT; ++i) {
+                const int pk = xvo[i];
+                if (i * 256 < nxv && pk < 0) {
+                    const int row = (pk >> 20) & 0x7FF, v4 = pk & 0xFFFFF;
+                    f32x4 v = xv[i];
+                    const int c = c0 + row;
+                    const bool s1 = c >= a.C0;
+                    if (xedge || ctail) {
+                        const int t0 = (s1 ? e01 - a.off1 : e00 - a.off0) + v4;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (c >= Ctot || t0 + k < 0 || t0 + k >= a.Tin) v[k] = 0.f;
+                    }
+                    if (!deint) {
+                        *reinterpret_cast<f32x4*>(Xs + bufoff + row * XP + v4) = v;
+                    } else {
+                        // plane 0 = even samples of the window, plane 1 = odd ones; an odd sub-vector shift swaps
+                        // which half of the vector is which (the residual shift is folded into the read offsets)
+                        const bool odd = ((s1 ? dl1 : dl0) & 1) != 0;
+                        const float2 pe = odd ? make_float2(v[1], v[3]) : make_float2(v[0], v[2]);
+                        const float2 po = odd ? make_float2(v[0], v[2]) : make_float2(v[1], v[3]);
+                        float* xd = Xs + bufoff + row * XP + (v4 >> 1);
+                        *reinterpret_cast<float2*>(xd) = pe;
+                        *reinterpret_cast<float2*>(xd + CH * XP) = po;
+                    }
+                }
+            }
+        } else if (!deint) {
             const int lr = tid % TPR;
             float* xd = Xs + bufoff + xrow * XP + lr;
 #pragma unroll
@@ -446,9 +533,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
         }
     }
     const bool skip_last_odd = deint && CK == 8 && (a.KW & 1);     // the odd phase has no tap KW
-    auto run_taps = [&](int bufoff, int j_begin, int j_end) {
+    auto run_taps = [&](int bufoff, int j_begin, int j_end, int dlt) {
         if (j_end <= j_begin) return;
-        const float* xa = Xs + bufoff + lg * XP + (FOLD ? 0 : wt0 + li) + j_begin;   // tap j, rows 0..3
+        // (XVEC: dlt = sub-vector shift of the chunk's source; stride-2 planes hold it as dlt>>1 / (dlt+1)>>1)
+        const float* xa = Xs + bufoff + lg * XP + (FOLD ? 0 : wt0 + li) + j_begin + (deint ? (dlt >> 1) : dlt);   // tap j, rows 0..3
+        const int x2off = 4 * XP + (deint ? (dlt & 1) : 0);                          // rows 4..7 of the same tap
+        (void)x2off;
         const float* wb = Ws + bufoff + (j_begin * CK + lg) * WP + wn0 + li;
         const int wstep = CK * WP;
         float a0[MT], b0[NW], a1[MT], b1[NW];
@@ -492,7 +582,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
             for (int j = j_begin; j < j_full; ++j) {
                 const bool more = j + 1 < j_end;
                 mm_first(a0, b0);
-                ldop(xa + 4 * XP, wb + 4 * WP, a1, b1);                 // rows 4..7 of tap j
+                ldop(xa + x2off, wb + 4 * WP, a1, b1);                  // rows 4..7 of tap j
                 mm_rest(a0, b0);
                 pin();
                 xa += more ? 1 : 0;                                     // next tap (clamped at the end)
@@ -536,7 +626,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
     WUN_TRACE_STAMP(7);
     if (ch_lo < ch_hi && !ab_noload) load_chunk(ch_lo);
     WUN_TRACE_STAMP(8);
-    if (ch_lo < ch_hi && !ab_nostore) store_chunk(0);
+    if (ch_lo < ch_hi && !ab_nostore) store_chunk(0, ch_lo);
     WUN_TRACE_STAMP(9);
     __syncthreads();
     WUN_TRACE_STAMP(1);
@@ -551,11 +641,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
         WUN_PRIO_HI();
         if (has_next && !ab_noload) load_chunk(chunk + 1);
         WUN_PRIO_LO();
-        if (!ab_nomfma) run_taps(cur, 0, half);
+        const int dlt = XVEC ? ((chunk * CKC < a.C0) ? dl0 : dl1) : 0;
+        if (!ab_nomfma) run_taps(cur, 0, half, dlt);
         WUN_PRIO_HI();
-        if (has_next && !ab_nostore) store_chunk(LB - cur);
+        if (has_next && !ab_nostore) store_chunk(LB - cur, chunk + 1);
         WUN_PRIO_LO();
-        if (!ab_nomfma) run_taps(cur, half, J);
+        if (!ab_nomfma) run_taps(cur, half, J, dlt);
         if (!ab_nobar) __syncthreads();
     }
     WUN_TRACE_STAMP(2);
@@ -618,11 +709,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
                                 v[4 + r] *= (m1[r] > 0.f) ? 1.f : 0.2f;
                             }
                         }
-                        if (accum2) {
+                        const int pos0 = a.ooff0 + t0;
+                        if (accum2 && (conv_acc_at(a, pos0) || conv_acc_at(a, pos0 + 7))) {      // (the window is wider than 8)
                             const f32x4 o0 = *reinterpret_cast<const f32x4*>(&a.dst0[idx]);
                             const f32x4 o1 = *reinterpret_cast<const f32x4*>(&a.dst0[idx + 4]);
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) { v[r] += o0[r]; v[4 + r] += o1[r]; }
+                            for (int r = 0; r < 4; ++r) {
+                                if (conv_acc_at(a, pos0 + r)) v[r] += o0[r];
+                                if (conv_acc_at(a, pos0 + 4 + r)) v[4 + r] += o1[r];
+                            }
                         }
                         *reinterpret_cast<f32x4*>(&a.dst0[idx]) = (f32x4){v[0], v[1], v[2], v[3]};
                         *reinterpret_cast<f32x4*>(&a.dst0[idx + 4]) = (f32x4){v[4], v[5], v[6], v[7]};
@@ -633,7 +728,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
                                 const long long idx = rowbase + t0 + r;
                                 float x = v[r];
                                 if (a.msk0 != nullptr) x *= (a.msk0[idx] > 0.f) ? 1.f : 0.2f;
-                                if (accum2) x += a.dst0[idx];
+                                if (accum2 && conv_acc_at(a, a.ooff0 + t0 + r)) x += a.dst0[idx];
                                 a.dst0[idx] = x;
                             }
                         }
@@ -681,7 +776,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
                         if (lrelu) v = fmaxf(0.2f * v, v);
                         const long long idx = (long long)g * obs + colbase + (long long)qq * a.ostride;
                         if (msk != nullptr) v *= (msk[idx] > 0.f) ? 1.f : 0.2f;
-                        if (accum) v += dst[idx];
+                        if (accum && conv_acc_at(a, (first ? a.ooff0 : a.ooff1) + qq * a.ostride)) v += dst[idx];
                         dst[idx] = v;
                         if (a.dec != nullptr && first && (qq & 1) == 0)
                             a.dec[(long long)g * a.decbs + (long long)ncol * a.decpitch + (qq >> 1)] = v;
@@ -701,10 +796,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] *= (mk[r] > 0.f) ? 1.f : 0.2f;
                 }
-                if (accum) {
+                const int pos0 = (ncol < a.N0 ? a.ooff0 : a.ooff1) + q;                 // vector path: ostride == 1
+                if (accum && (conv_acc_at(a, pos0) || conv_acc_at(a, pos0 + 3))) {
                     const f32x4 old = *reinterpret_cast<const f32x4*>(&dst[idx]);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += old[r];
+                    for (int r = 0; r < 4; ++r)
+                        if (conv_acc_at(a, pos0 + r)) v[r] += old[r];
                 }
                 *reinterpret_cast<f32x4*>(&dst[idx]) = v;
                 if (decrow != nullptr) {
@@ -719,7 +816,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
                         if (lrelu) v = fmaxf(0.2f * v, v);
                         const long long idx = rowbase + (long long)(q + r) * a.ostride;
                         if (msk != nullptr) v *= (msk[idx] > 0.f) ? 1.f : 0.2f;
-                        if (accum) v += dst[idx];
+                        if (accum && conv_acc_at(a, (ncol < a.N0 ? a.ooff0 : a.ooff1) + (q + r) * a.ostride)) v += dst[idx];
                         dst[idx] = v;
                         if (decrow != nullptr && ((q + r) & 1) == 0) decrow[(q + r) >> 1] = v;
                     }
@@ -759,7 +856,9 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvArgs a, i
         const bool vpath = vec && q + 3 < a.Tout;
         f32x4 mk = {1.f, 1.f, 1.f, 1.f}, old = {0.f, 0.f, 0.f, 0.f};
         if (vpath && msk != nullptr) mk = *reinterpret_cast<const f32x4*>(&msk[rowbase + q]);
-        if (vpath && accum) old = *reinterpret_cast<const f32x4*>(&dst[rowbase + q]);
+        const int pos0 = (ncol < a.N0 ? a.ooff0 : a.ooff1) + q * a.ostride;
+        const bool acc_v = accum && (conv_acc_at(a, pos0) || conv_acc_at(a, pos0 + 3));       // vector path: ostride == 1
+        if (vpath && acc_v) old = *reinterpret_cast<const f32x4*>(&dst[rowbase + q]);
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         const float* pp = a.part + bn * TP + q;
         // the loads of a batch are all in flight before the first add (a load + wait per split made this kernel
@@ -800,7 +899,11 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvArgs a, i
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] *= (mk[r] > 0.f) ? 1.f : 0.2f;
             }
-            if (accum) v += old;
+            if (acc_v) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (conv_acc_at(a, pos0 + r)) v[r] += old[r];
+            }
             *reinterpret_cast<f32x4*>(&dst[idx]) = v;
             if (a.dec != nullptr && ncol < a.N0) {
                 float* decrow = a.dec + (long long)b * a.decbs + (long long)ncol * a.decpitch;
@@ -814,7 +917,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvArgs a, i
                     const long long idx = rowbase + (long long)(q + r) * a.ostride;
                     float x = v[r];
                     if (msk != nullptr) x *= (msk[idx] > 0.f) ? 1.f : 0.2f;
-                    if (accum) x += dst[idx];
+                    if (accum && conv_acc_at(a, pos0 + r * a.ostride)) x += dst[idx];
                     dst[idx] = x;
                     if (a.dec != nullptr && ncol < a.N0 && ((q + r) & 1) == 0)
                         a.dec[(long long)b * a.decbs + (long long)ncol * a.decpitch + ((q + r) >> 1)] = x;
@@ -971,7 +1074,29 @@ void conv_splitk(const ConvArgs& a, int variant, long long part_cap_floats, int&
     if (ksplit < 2) { ksplit = 1; cps = nchunks; }
 }
 
-template <int MT, int NW, int WT, int WN, int CK, bool VECW, bool FOLD = false>
+// Vector (16-byte) paths need aligned bases / pitches; everything the plan allocates is.
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// may this launch use the vector-staging instantiation (XVEC) of tile `variant`?
+static bool conv_xvec_ok(const ConvArgs& a, int variant) {
+    const ConvVariant& cv = kConvVariants[variant];
+    const int Ctot = a.C0 + a.C1;
+    if (cv.fold || Ctot <= 4 || cv.CK != 8 || getenv("WUN_XVEC") == nullptr) return false;   // opt-in: measured 2.7 % SLOWER per step
+    if (!aligned16(a.src0) || (a.bs0 & 3) != 0 || (a.pitch0 & 3) != 0) return false;
+    if (a.src1 != nullptr && (!aligned16(a.src1) || (a.bs1 & 3) != 0 || (a.pitch1 & 3) != 0)) return false;
+    if (a.off0 < 0 || a.off1 < 0) return false;
+    const bool deint = a.loader == LOADER_DEINT;
+    const int CKC = deint ? cv.CK / 2 : cv.CK;
+    const int dl0 = (((a.off0 - a.shift) % 4) + 4) % 4, dl1 = a.C1 > 0 ? (((a.off1 - a.shift) % 4) + 4) % 4 : dl0;
+    if (a.C1 > 0 && dl0 != dl1 && (a.C0 % CKC) != 0) return false;      // a chunk would mix two sub-vector shifts
+    int TT, NT, J, XP, WP;
+    conv_geom(a, variant, TT, NT, J, XP, WP);
+    const int span = deint ? 2 * (TT + J - 1) : TT + J - 1;
+    const int nvr = (span + (dl0 > dl1 ? dl0 : dl1) + 3) / 4;
+    return (deint ? 2 * nvr : 4 * nvr) <= XP;                             // the vectors of a row stay inside its LDS pitch
+}
+
+template <int MT, int NW, int WT, int WN, int CK, bool VECW, bool FOLD = false, bool XVEC = false>
 static hipError_t conv_launch_t(ConvArgs a, int variant, float* part, long long part_cap, hipStream_t s) {
     int TT, NT, J, XP, WP;
     conv_geom(a, variant, TT, NT, J, XP, WP);
@@ -981,7 +1106,7 @@ static hipError_t conv_launch_t(ConvArgs a, int variant, float* part, long long 
     const int nNT = phase2 ? (a.N + NT / 2 - 1) / (NT / 2) : (a.N + NT - 1) / NT;
     const size_t lds = conv_lds_bytes(a, variant);
     if (FOLD && !conv_fold_ok(a, variant)) return hipErrorInvalidValue;
-    auto kern = conv_mfma_kernel<MT, NW, WT, WN, CK, VECW, FOLD>;
+    auto kern = conv_mfma_kernel<MT, NW, WT, WN, CK, VECW, FOLD, XVEC>;
     static size_t lds_allowed = 64 * 1024;
     if (lds > lds_allowed) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1017,8 +1142,8 @@ static hipError_t conv_launch_t(ConvArgs a, int variant, float* part, long long 
     const long long grid = (long long)nTT * nNT * bfac * ksplit;
     if (grid <= 0) return hipSuccess;
     char nm[64];
-    snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %s%s>", MT, NW, WT, WN, CK, VECW ? "true" : "false",
-             FOLD ? ", fold" : "");
+    snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %s%s%s>", MT, NW, WT, WN, CK, VECW ? "true" : "false",
+             FOLD ? ", fold" : "", XVEC ? ", xvec" : "");
     {
         char tag[160];
         snprintf(tag, sizeof(tag), "C=%d N=%d T=%d K=%d ld=%d B=%d ks=%d ph2=%d acc=%d os=%d grid=%lld", a.C0 + a.C1, a.N,
@@ -1082,11 +1207,10 @@ int conv_list_candidates(const ConvArgs& a, long long part_cap, ConvChoice* out,
 
 int conv_num_variants() { return (int)(sizeof(kConvVariants) / sizeof(kConvVariants[0])); }
 
-// Vector (16-byte) paths need aligned bases / pitches; everything the plan allocates is.
-static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 hipError_t launch_conv(const ConvArgs& a_in, float* part, long long part_cap, hipStream_t s) {
     ConvArgs a = a_in;
+    if (a.acc_len == 0) { a.acc_lo = 0; a.acc_len = 0x7FFFFFFFu; }          // F_ACCUM over the whole row (default)
     if (conv_J(a) > WUN_JMAX) return hipErrorInvalidValue;       // rejected at plan creation
     if (a.KW <= 0) {
         // no taps (odd output phase of a transposed stride-2 conv with filter_size 1): the conv is the
@@ -1133,21 +1257,25 @@ hipError_t launch_conv(const ConvArgs& a_in, float* part, long long part_cap, hi
             default: return conv_launch_t<1, 2, 4, 1, 4, false>(a, v, part, part_cap, s);
         }
     }
-#define WUN_CV(i, MT, NW, WT, WN, CK) case i: return conv_launch_t<MT, NW, WT, WN, CK, true>(a, v, part, part_cap, s);
+    const bool xv = conv_xvec_ok(a, v);
+#define WUN_CV(i, MT, NW, WT, WN, CK) case i: \
+        if (xv) return conv_launch_t<MT, NW, WT, WN, CK, true, false, true>(a, v, part, part_cap, s); \
+        return conv_launch_t<MT, NW, WT, WN, CK, true>(a, v, part, part_cap, s);
+#define WUN_CV4(i, MT, NW, WT, WN, CK) case i: return conv_launch_t<MT, NW, WT, WN, CK, true>(a, v, part, part_cap, s);
     switch (v) {
         WUN_CV(0, 4, 2, 4, 1, 8) WUN_CV(1, 4, 3, 4, 1, 8) WUN_CV(2, 4, 4, 4, 1, 8) WUN_CV(3, 4, 5, 4, 1, 8)
         WUN_CV(4, 2, 2, 4, 1, 8) WUN_CV(5, 2, 3, 4, 1, 8) WUN_CV(6, 2, 4, 4, 1, 8) WUN_CV(7, 2, 5, 4, 1, 8)
         WUN_CV(8, 1, 2, 4, 1, 8) WUN_CV(9, 1, 3, 4, 1, 8)
         WUN_CV(10, 1, 2, 2, 2, 8) WUN_CV(11, 1, 3, 2, 2, 8)
         WUN_CV(12, 1, 2, 1, 4, 8)
-        WUN_CV(13, 4, 2, 4, 1, 4) WUN_CV(14, 1, 2, 4, 1, 4)
+        WUN_CV4(13, 4, 2, 4, 1, 4) WUN_CV4(14, 1, 2, 4, 1, 4)
         WUN_CV(15, 2, 6, 4, 1, 8) WUN_CV(16, 4, 6, 4, 1, 8)
         WUN_CV(17, 3, 2, 4, 1, 8) WUN_CV(18, 3, 3, 4, 1, 8) WUN_CV(19, 3, 4, 4, 1, 8) WUN_CV(20, 3, 5, 4, 1, 8)
         WUN_CV(21, 3, 6, 4, 1, 8)
         WUN_CV(22, 5, 2, 4, 1, 8) WUN_CV(23, 5, 3, 4, 1, 8)
         WUN_CV(24, 6, 2, 4, 1, 8) WUN_CV(25, 6, 3, 4, 1, 8)
-        WUN_CV(26, 4, 3, 4, 1, 4) WUN_CV(27, 2, 3, 4, 1, 4) WUN_CV(28, 3, 3, 4, 1, 4) WUN_CV(29, 2, 2, 4, 1, 4)
-        WUN_CV(30, 3, 2, 4, 1, 4) WUN_CV(31, 4, 5, 4, 1, 4) WUN_CV(32, 3, 5, 4, 1, 4) WUN_CV(33, 2, 5, 4, 1, 4)
+        WUN_CV4(26, 4, 3, 4, 1, 4) WUN_CV4(27, 2, 3, 4, 1, 4) WUN_CV4(28, 3, 3, 4, 1, 4) WUN_CV4(29, 2, 2, 4, 1, 4)
+        WUN_CV4(30, 3, 2, 4, 1, 4) WUN_CV4(31, 4, 5, 4, 1, 4) WUN_CV4(32, 3, 5, 4, 1, 4) WUN_CV4(33, 2, 5, 4, 1, 4)
 #define WUN_CF(i, MT, NW, WT, WN, CK) case i: return conv_launch_t<MT, NW, WT, WN, CK, true, true>(a, v, part, part_cap, s);
         WUN_CF(34, 1, 2, 4, 1, 8) WUN_CF(35, 1, 3, 4, 1, 8) WUN_CF(36, 2, 2, 4, 1, 8) WUN_CF(37, 2, 3, 4, 1, 8)
         WUN_CF(38, 2, 3, 2, 2, 8) WUN_CF(39, 4, 3, 2, 2, 8) WUN_CF(40, 2, 2, 2, 2, 8) WUN_CF(41, 4, 2, 2, 2, 8)
@@ -1155,6 +1283,7 @@ hipError_t launch_conv(const ConvArgs& a_in, float* part, long long part_cap, hi
         default: return hipErrorInvalidValue;
     }
 #undef WUN_CV
+#undef WUN_CV4
 }
 
 // =====================================================================================

@@ -140,6 +140,7 @@ struct wun_plan {
     mutable hipEvent_t wt_ev = nullptr;
     mutable bool wt_ready = false;
     mutable std::vector<hipEvent_t> skip_ev;             // forward: skip window i is complete (deferred window convs)
+    mutable std::vector<hipEvent_t> win_ev;              // backward: the early skip-window input gradient of level i is complete
     // bf16-MFMA speed mode (cfg.compute_dtype == 1): packed bf16 images of the conv weights in the
     // workspace, keyed by where the fp32 weights of a launch live (params arena / transposed copy in ws)
     struct BfImg { long long off; int c8p, npad; };
@@ -442,6 +443,7 @@ extern "C" void wun_plan_destroy(wun_plan* p) {
     if (p->tev0) { (void)hipEventDestroy(p->tev0); (void)hipEventDestroy(p->tev1); }
     if (p->wt_ev) (void)hipEventDestroy(p->wt_ev);
     for (auto e : p->skip_ev) (void)hipEventDestroy(e);
+    for (auto e : p->win_ev) (void)hipEventDestroy(e);
     if (p->side) (void)hipStreamDestroy(p->side);
     if (p->side2) (void)hipStreamDestroy(p->side2);
     delete p;
@@ -1014,10 +1016,40 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
     // 2-5), so the default stays one event per level.
     struct PendingWgrad { WgradArgs w[2]; int n; const ConvLayer* cl; };
     std::vector<PendingWgrad> pend;
+    // Early skip-window input gradients (context mode).  The input gradient of down level i is the transposed stride-2
+    // conv of dz_dec[i] over the whole row PLUS the full-rate conv of dz_skip[i] over the crop window.  dz_skip[i] is
+    // final as soon as up level L-1-i's input gradient has run -- the shallow, FLOP-heavy levels' at the very start of
+    // the backward pass -- while the row-wide part can only run when the dependent chain reaches level i at its very
+    // end.  The window part is therefore launched as soon as its input exists, on the side streams (it fills the
+    // launch-latency-bound deep part of the chain instead of lengthening the FLOP-bound end of it), stores into the
+    // window of dz_dec[i-1], and the row-wide conv later ADDS inside the window (ConvArgs.acc_lo / acc_len) and stores
+    // outside it: a + b == b + a, results are bit-identical to the old order.  Queued here, issued by the next flush
+    // (whose event already orders the side streams behind the producing kernels: no extra packet on the chain).
+    // Measured (round 3, same-box A/B, tuned tables per arm): 8.98 vs 8.99 ms per step -- the step is bound by the aggregate
+    // throughput of the MFMA kernels, not by the length of the chain, so moving 0.46 ms of work off the chain buys nothing.
+    // Kept as an option (WUN_EARLY_WINDOW=1; changes the launch order, i.e. needs its own tuning table).
+    const bool early_win = !same && !p->bf16 && getenv("WUN_EARLY_WINDOW") != nullptr;
+    if (early_win && p->win_ev.size() < (size_t)L) {
+        p->win_ev.resize(L, nullptr);
+        for (auto& e : p->win_ev)
+            if (!e) HIP_TRY(hipEventCreateWithFlags(&e, event_flags()));
+    }
+    std::vector<int> pend_win;
+    const long long cpart_half = p->conv_part_floats / 2, cpart_q = p->conv_part_floats / 4;
+    auto window_dgrad_args = [&](int i) {
+        const DownShape& d = p->dsh[i];
+        const ConvLayer& cl = p->down[i];
+        ConvArgs a = conv_base(p);
+        set_src0(a, ws, p->dz_skip[i], 0, d.cout);
+        a.Tin = d.tc; a.shift = Kd - 1; a.W = ws + cl.wt_full; a.KW = Kd;
+        a.N = a.N0 = d.cin; a.Tout = d.tc + Kd - 1;
+        set_dst0(a, ws, p->dz_dec[i - 1], d.cs, &p->dec[i - 1]);
+        return a;
+    };
     static const int wg_batch = getenv("WUN_WG_BATCH") ? atoi(getenv("WUN_WG_BATCH")) : 1;
     static const long long wg_batch_rows = getenv("WUN_WG_BATCH_ROWS") ? atoll(getenv("WUN_WG_BATCH_ROWS")) : 16384;
     auto flush_wgrads = [&]() -> int {
-        if (pend.empty()) return WUN_OK;
+        if (pend.empty() && pend_win.empty()) return WUN_OK;
         if (s2 != s) {
             hipEvent_t e = p->events[p->ev_next++ % p->events.size()];
             HIP_TRY(hipEventRecord(e, s));
@@ -1030,6 +1062,14 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
             if ((rcq = ready2(q.cl->woff))) return rcq;
         }
         pend.clear();
+        for (int i : pend_win) {
+            // own quarter of the split-K scratch per side stream (the chain on `s` uses the first half)
+            hipStream_t sw = wstream();
+            float* part = ws + p->conv_part_off + cpart_half + ((sw == s3 && s3 != s2) ? cpart_q : 0);
+            HIP_TRY(conv_dispatch(p, window_dgrad_args(i), sw == s ? ws + p->conv_part_off : part, sw == s ? cpart_half : cpart_q, sw));
+            if (sw != s) HIP_TRY(hipEventRecord(p->win_ev[(size_t)i], sw));
+        }
+        pend_win.clear();
         return WUN_OK;
     };
     auto submit_wgrad = [&](const WgradArgs* w, int n, const ConvLayer& cl) -> int {
@@ -1110,6 +1150,7 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
             set_dst0(a, ws, p->dz_skip[i], 0, &p->skip[i]);
             set_dst1(a, ws, p->d_ups[j], 0, nullptr);
             HIP_TRY(conv_dispatch(p, a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
+            if (early_win && i > 0) pend_win.push_back(i);     // dz_skip[i] is final: its window input gradient can start
         }
         {
             const Buf& prev = (j == 0) ? p->bott_out : p->upo[j - 1];
@@ -1212,6 +1253,12 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
                 f.Tin = d.t_dec; f.KW = cl.J0; f.kw_full = Kd; f.shift = cl.J0 - 1; f.W = ws + cl.wt_ph2;
                 f.N = f.N0 = d.cin; f.Tout = (d.t_in + 1) / 2; f.Tlim = d.t_in; f.flags = F_PHASE2;
                 set_dst0(f, ws, p->dz_dec[i - 1], 0, &p->dec[i - 1]);
+                const bool win_early = early_win && !p->win_ev.empty();
+                if (win_early) {
+                    // the window part is already in dz_dec[i-1] (side stream): wait for it, add inside the window
+                    if (s2 != s) HIP_TRY(hipStreamWaitEvent(s, p->win_ev[(size_t)i], 0));
+                    f.flags |= F_ACCUM; f.acc_lo = d.cs; f.acc_len = (unsigned)(d.tc + Kd - 1);
+                }
                 // (bf16 mode: always fused when the channel count allows -- one launch, the gradient tile staged once,
                 //  contiguous 32-byte stores instead of two stride-2 scatter passes)
                 if ((d.cin & 3) == 0 && ((p->bf16 && conv_bf16_preferred(f, p->bf16_min_rows)) ||
@@ -1225,16 +1272,15 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
                         a.N = a.N0 = d.cin; a.Tout = (d.t_in - ph + 1) / 2;
                         set_dst0(a, ws, p->dz_dec[i - 1], ph, &p->dec[i - 1]);
                         a.ostride = 2;
+                        if (win_early) { a.flags |= F_ACCUM; a.acc_lo = d.cs; a.acc_len = (unsigned)(d.tc + Kd - 1); }
                         HIP_TRY(conv_dispatch(p, a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
                     }
                 }
-                ConvArgs a = conv_base(p);
-                set_src0(a, ws, p->dz_skip[i], 0, d.cout);
-                a.Tin = d.tc; a.shift = Kd - 1; a.W = ws + cl.wt_full; a.KW = Kd;
-                a.N = a.N0 = d.cin; a.Tout = d.tc + Kd - 1;
-                set_dst0(a, ws, p->dz_dec[i - 1], d.cs, &p->dec[i - 1]);
-                a.flags = F_ACCUM;
-                HIP_TRY(conv_dispatch(p, a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
+                if (!win_early) {
+                    ConvArgs a = window_dgrad_args(i);
+                    a.flags = F_ACCUM;
+                    HIP_TRY(conv_dispatch(p, a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
+                }
             }
         }
     }
