@@ -251,6 +251,67 @@ def test_conv_every_variant_fused_two_phase_dgrad(lib, case):
     record("conv_every_variant_fused_two_phase", str(case), worst[0], OP_TOL)
 
 
+DMA_CASES = [
+    # (B, C0, C1, Cout, K, T, pad_left): rows 16-byte aligned (T % 4 == 0), channel counts multiples of 8, so the
+    # stride-1 launches take the DMA staging path; pad_left 0..3 walks the sub-vector shift, pad_left > 0 and the
+    # overhanging last tile exercise the zero fix of the edge tiles, C1 > 0 the second source
+    (2, 24, 0, 48, 15, 800, 0), (2, 16, 24, 40, 5, 420, 2), (3, 72, 0, 80, 15, 432, 7), (2, 8, 8, 24, 15, 1000, 1),
+    (2, 40, 0, 96, 5, 404, 3), (4, 32, 16, 56, 9, 640, 4),
+]
+
+
+@pytest.mark.parametrize("case", DMA_CASES, ids=[str(c) for c in DMA_CASES])
+def test_conv_dma_staging_equals_register_staging(lib, case, monkeypatch):
+    """The DMA instantiations (global -> LDS directly, sub-vector shift folded into the operand offset, edge tiles zeroed
+    after landing) against the register-staged instantiations of the SAME tile (WUN_NO_DMA=1): the MFMA stream is the
+    same, so the results must agree BIT FOR BIT -- for every variant x split-K the dispatcher accepts -- and both match
+    the float64 reference."""
+    B, C0, C1, Cout, K, T, pad = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31) + 21)
+    x0 = rng.uniform(-1, 1, (B, C0, T)).astype(np.float32)
+    x1 = rng.uniform(-1, 1, (B, max(C1, 1), T)).astype(np.float32)
+    w = (rng.uniform(-1, 1, (K, C0 + C1, Cout)) / np.sqrt(K * (C0 + C1))).astype(np.float32)
+    bias = rng.uniform(-0.1, 0.1, Cout).astype(np.float32)
+    t_out = T - K + 1 + min(pad, K - 1)                 # some zero padding on the left, valid on the right
+    xcat = np.concatenate([x0, x1[:, :C1]], axis=1) if C1 > 0 else x0
+    ref = _conv64(xcat, w, bias, 1, pad, t_out)
+    ref = torch.maximum(0.2 * ref, ref).numpy()
+    scale = max(1.0, np.abs(ref).max())
+    d0, d1, dw, db_ = _cuda(x0), _cuda(x1), _cuda(w), _cuda(bias)
+    y = torch.empty((B, Cout, t_out), device="cuda")
+    nvar = lib.wun_op_num_conv_variants()
+    compared = 0
+    try:
+        for v in range(nvar):
+            for ks in (1, 3):
+                lib.wun_op_force_conv_variant(v, ks)
+                outs = []
+                for no_dma in (False, True):
+                    if no_dma:
+                        monkeypatch.setenv("WUN_NO_DMA", "1")
+                    else:
+                        monkeypatch.delenv("WUN_NO_DMA", raising=False)
+                    y.fill_(float("nan"))
+                    rc = lib.wun_op_conv1d_ex(d0.data_ptr(), C0, d1.data_ptr() if C1 > 0 else None, C1, dw.data_ptr(),
+                                              db_.data_ptr(), y.data_ptr(), None, B, Cout, K, T, t_out, t_out, 1, pad, 1, 0,
+                                              1, 0, _stream())
+                    if rc != 0:
+                        outs = []
+                        break
+                    torch.cuda.synchronize()
+                    outs.append(y.cpu().numpy().copy())
+                if not outs:
+                    continue
+                assert np.isfinite(outs[0]).all(), (v, ks)
+                assert np.array_equal(outs[0], outs[1]), (v, ks, np.abs(outs[0] - outs[1]).max())
+                assert np.abs(outs[0] - ref).max() / scale <= OP_TOL, (v, ks)
+                compared += 1
+    finally:
+        lib.wun_op_force_conv_variant(-1, 0)
+        monkeypatch.delenv("WUN_NO_DMA", raising=False)
+    assert compared >= 4
+
+
 def test_every_conv_variant_was_exercised(lib):
     nvar = lib.wun_op_num_conv_variants()
     missing = [v for v in range(nvar) if v not in _RAN_CONV]

@@ -8,7 +8,7 @@ lib = _lib.load()
 lib.wun_dbg_trace_read.restype = C.c_int; lib.wun_dbg_trace_read.argtypes = [C.c_void_p, C.c_int, C.c_int]
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 B = 16
-LAYERS = [("fwd_s2_72_96", "fwd", 72, 96, 15, 18421, 2, 18), ("dgrad_s2_96_120", "dgrad", 96, 120, 15, 9204, 2, -1)]
+LAYERS = [("up9_168_72_k5", "fwd", 168, 72, 5, 4108, 1, 18), ("win3_72_96_k15", "fwd", 72, 96, 15, 2076, 1, 18), ("dgrad_s2_96_120", "dgrad", 96, 120, 15, 9205, 2, -1)]
 
 def make(kind, cin, cout, k, t, stride):
     t_out = (t - k) // stride + 1
@@ -35,7 +35,7 @@ def trace(fn, abl):
 for name, kind, cin, cout, k, t, stride, variant in LAYERS:
     fn, flops, keep = make(kind, cin, cout, k, t, stride)
     lib.wun_op_force_conv_variant(variant, 1 if variant >= 0 else 0)
-    for abl, what in ((0, "baseline"), (128, "hot loads"), (256, "hot stores"), (8, "no epilogue"), (3, "no staging"), (27, "MFMA only")):
+    for abl, what in ((0, "baseline"), (8, "no epilogue"), (1, "no DMA / loads"), (4, "no MFMA")):
         u = trace(fn, abl)
         mhz = np.median((u[:, 3] - u[:, 0]) / np.maximum(1, (u[:, 6] - u[:, 5]))) * 100
         f = lambda a, b_: np.median(u[:, a] - u[:, b_]) / mhz

@@ -186,11 +186,17 @@ __device__ __forceinline__ int fast_div(int n, int d, float inv) {
 // offsets and the epilogue's (excerpt, position) decode differ from the plain kernel.
 #define WUN_FOLD_XCAP(TT) (3 * (TT) + 32)      // LDS input-row capacity of a FOLD tile (floats per plane)
 
-// XVEC: the input window is staged with 16-byte global loads / wide LDS stores (rows of the plan's buffers are
-// 16-byte aligned): the window starts at the aligned element below its first sample and the sub-vector shift
-// (launch-constant per source: (off - shift) mod 4) is folded into the A-operand LDS offset; the stride-2 loader
-// splits every vector into its two even / two odd samples (two 8-byte stores).  A quarter of the load, store
-// and mask instructions of the element-wise path, which stays for FOLD tiles and unaligned test tensors.
+// XVEC ("DMA" instantiations, stride-1 loader): the input window and the weight slab of a chunk go global -> LDS
+// DIRECTLY (global_load_lds, 16 bytes per lane, one contiguous KiB of LDS per wave instruction): no staging
+// registers, no LDS store instructions, no per-chunk mask / address VALU -- per chunk a wave issues a handful of
+// DMA instructions right after the barrier and then runs ONE uninterrupted tap loop.  The window starts at the
+// aligned element below its first sample (rows of the plan's buffers are 16-byte aligned) and the sub-vector shift
+// (launch-constant per source: (off - shift) mod 4) is folded into the A-operand LDS offset.  Samples outside
+// [0, Tin) ('same' padding, the halo of a transposed conv) are zeroed in LDS after the DMA has landed, by the edge
+// tiles only.  The element-wise register path stays for the stride-2 loader, FOLD tiles, channel tails and
+// unaligned test tensors.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
 template <int MT, int NW, int WT, int WN, int CK, bool VECW, bool FOLD = false, bool XVEC = false>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int nNT, int J,
                                                         int XP, int WP) {
@@ -206,13 +212,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
     constexpr int XIT_I = FOLD ? (2 * WUN_FOLD_XCAP(TT) + TPC - 1) / TPC
                                : (2 * (TT + (WUN_JMAX + 1) / 2 - 1) + TPC - 1) / TPC;
     constexpr int XIT = XVEC ? 1 : (XIT_D > XIT_I ? XIT_D : XIT_I);
-    constexpr int WIT = (WUN_JMAX * CK * NT4 + 255) / 256;
-    // XVEC: 16-byte vectors per LDS row (upper bounds for J <= WUN_JMAX and any sub-vector shift) and per thread
-    constexpr int NVR_D = (TT + WUN_JMAX - 1 + 3 + 3) / 4;
-    constexpr int NVR_I = (2 * (TT + (WUN_JMAX + 1) / 2 - 1) + 3 + 3) / 4;
-    constexpr int XVIT_D = (CK * NVR_D + 255) / 256, XVIT_I = (CH * NVR_I + 255) / 256;
-    constexpr int XVIT = XVEC ? (XVIT_D > XVIT_I ? XVIT_D : XVIT_I) : 1;
-    static_assert(!(XVEC && FOLD), "vector staging is not implemented for batch-folded tiles");
+    constexpr int WIT = XVEC ? 1 : (WUN_JMAX * CK * NT4 + 255) / 256;
+    // XVEC: 16-byte granules per thread -- X: CK rows of at most (TT + 48) / 4 granules (the LDS pitch), W: J * CK rows of
+    // at most NT / 4 + 4 granules
+    constexpr int XDIT = XVEC ? (CK * ((TT + 48) / 4) + 255) / 256 : 1;
+    constexpr int WDIT = XVEC ? (WUN_JMAX * CK * (NT4 + 4) + 255) / 256 : 1;
+    static_assert(!(XVEC && FOLD), "DMA staging is not implemented for batch-folded tiles");
 
     // two LDS buffers {input window, weight slab}: chunk c+1 is written while chunk c is read
     const int XB = CK * XP, LB = CK * XP + J * CK * WP;      // floats per X tile / per buffer
@@ -310,31 +315,71 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
     int xt[XIT];
     unsigned xmask_s = 0, wmask_s = 0;
     const int xrow = deint ? tid / TPC : tid / TPR;       // LDS row (DIRECT) / channel (DEINT) staged by this thread
-    // XVEC state: sub-vector shift of each source, aligned element index of the window start in a source row,
-    // vectors per LDS row, and per staged vector ONE packed register: bit 31 = live | row << 20 | 4 * vector index
+    // XVEC state: sub-vector shift of each source, aligned element index of the window start in a source row, granules
+    // per LDS row that are fetched, and per granule of this thread its global element offset (chunk-invariant; the
+    // chunk only moves a uniform base) or -1 for a lane that fetches nothing
     const int dl0 = XVEC ? (((a.off0 - a.shift) % 4) + 4) % 4 : 0;
     const int dl1 = (XVEC && a.C1 > 0) ? (((a.off1 - a.shift) % 4) + 4) % 4 : dl0;
-    f32x4 xv[XVIT];
-    int xvo[XVIT];
+    int xdo[XDIT], wdo[WDIT];                                            // xdo: row << 20 | 4 * granule, or -1 (lane fetches nothing)
     int nvr = 1, e00 = 0, e01 = 0;
     bool xedge = false;
     const float* vb0 = a.src0 + (long long)b_ld * a.bs0;                 // row bases WITHOUT the crop offset (aligned)
     const float* vb1 = (a.src1 != nullptr) ? a.src1 + (long long)b_ld * a.bs1 : vb0;
+    // Stride-2 loader of the DMA instantiations ("s2"): the window stays CONTIGUOUS in LDS (row = one input channel,
+    // pitch 2 * XP) and the four k lanes of an MFMA are four consecutive TAPS of that channel: lane (i, k) reads
+    // x[2 * (t0 + i) + 4 * tg + k] -- banks 2i + k, conflict-free -- against the weight rows (ch, 4 * tg + k) of a slab
+    // laid out [channel][tap rounded up to 4][WP]; the taps past KW are zero rows written once at kernel start.
+    const bool s2 = XVEC && deint;
+    const int J16 = (a.KW + 3) & ~3;                                     // s2: taps per channel in LDS
+    const int XPR = s2 ? 2 * XP : XP;                                    // LDS row pitch of the input window
+    const int XROWS = s2 ? CH : CK;
+    const int XG = XPR >> 2, WG4 = WP >> 2;                              // granules per LDS row
     if constexpr (XVEC) {
-        const int tbase = (deint ? 2 * q0_ld : q0_ld) - a.shift;
-        const int span = deint ? 2 * UW : UW;
+        const int tbase = (s2 ? 2 * q0_ld : q0_ld) - a.shift;
+        const int span = s2 ? 2 * (TT - 1) + J16 : UW;
         nvr = (span + (dl0 > dl1 ? dl0 : dl1) + 3) >> 2;
         e00 = a.off0 + tbase - dl0;
         e01 = a.off1 + tbase - dl1;
         const int tf0 = tbase - dl0, tf1 = tbase - dl1;                  // time of the first staged element
         xedge = tf0 < 0 || tf0 + 4 * nvr > a.Tin || (a.C1 > 0 && (tf1 < 0 || tf1 + 4 * nvr > a.Tin));
-        const int rows = deint ? CH : CK;
-        const float inv_nvr = 1.0f / (float)nvr;
+        const float inv_xg = 1.0f / (float)XG;
 #pragma unroll
-        for (int i = 0; i < XVIT; ++i) {
+        for (int i = 0; i < XDIT; ++i) {
             const int f = tid + i * 256;
-            const int row = fast_div(f, nvr, inv_nvr), v = f - row * nvr;
-            xvo[i] = (row < rows) ? (int)(0x80000000u | ((unsigned)row << 20) | (unsigned)(v * 4)) : (int)((unsigned)(v * 4));
+            const int row = fast_div(f, XG, inv_xg), g = f - row * XG;
+            xdo[i] = (row < XROWS && g < nvr) ? (row << 20) | (4 * g) : -1;
+        }
+        const float inv_wg = 1.0f / (float)WG4;
+#pragma unroll
+        for (int i = 0; i < WDIT; ++i) {
+            const int f = tid + i * 256;
+            const int row = fast_div(f, WG4, inv_wg), c4 = f - row * WG4;
+            int j, r;
+            bool ok;
+            if (s2) { r = row / J16; j = row - r * J16; ok = r < CH && j < a.KW && c4 < NT4; }
+            else { j = row / CK; r = row - j * CK; ok = j < J && c4 < NT4; }
+            int wo;
+            if (!phase2) {
+                int col = n0 + c4 * 4;
+                col = col > a.N - 4 ? a.N - 4 : col;                     // padded columns: any valid (finite) weights
+                wo = (j * Ctot + r) * a.N + col;
+            } else {
+                const int x = c4 * 4, ph = x / (NT / 2), cl = x % (NT / 2);
+                int col = n0h + cl;
+                col = col > a.N - 4 ? a.N - 4 : col;
+                wo = (j * Ctot + r) * (2 * a.N) + ph * a.N + col;
+            }
+            wdo[i] = ok ? wo : -1;
+        }
+        if (s2 && J16 != a.KW) {
+            // zero rows of the taps [KW, J16) in both LDS buffers (never overwritten: their DMA lanes are idle)
+            const int nz = CH * (J16 - a.KW) * NT;
+            for (int f = tid; f < 2 * nz; f += 256) {
+                const int bsel = f >= nz ? 1 : 0, ff = f - bsel * nz;
+                const int col = ff % NT, rr = ff / NT;
+                const int r = rr / (J16 - a.KW), j = a.KW + rr % (J16 - a.KW);
+                Ws[bsel * LB + (r * J16 + j) * WP + col] = 0.f;
+            }
         }
     }
     if constexpr (!XVEC) {
@@ -364,7 +409,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
     int wr[WIT];              // channel index within the chunk (for the channel-tail mask)
     const int nwvec = J * CK * NT4;                       // weight vectors per chunk (uniform)
 #pragma unroll
-    for (int i = 0; i < WIT; ++i) {
+    for (int i = 0; i < (XVEC ? 0 : WIT); ++i) {
         const int f = tid + i * 256;
         const int row = f / NT4, c4 = f % NT4;
         const int j = row / CK, r = row % CK;
@@ -395,21 +440,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
     auto load_chunk = [&](int chunk) {
         const int c0 = chunk * CKC;
         if constexpr (XVEC) {
-            const int nxv = (deint ? CH : CK) * nvr;
-#pragma unroll
-            for (int i = 0; i < XVIT; ++i) {
-                if (i * 256 < nxv) {                       // uniform
-                    const int pk = xvo[i];
-                    int c = c0 + ((pk >> 20) & 0x7FF);
-                    c = c < Ctot ? c : Ctot - 1;           // rows past the tensor: any valid row (zeroed at the store)
-                    const bool s1 = c >= a.C0;
-                    const float* rp = s1 ? vb1 + (long long)(c - a.C0) * a.pitch1 : vb0 + (long long)c * a.pitch0;
-                    int e = (s1 ? e01 : e00) + (pk & 0xFFFFF);
-                    const int emax = (s1 ? a.pitch1 : a.pitch0) - 4;
-                    e = e < 0 ? 0 : (e > emax ? emax : e);
-                    xv[i] = *reinterpret_cast<const f32x4*>(rp + e);
-                }
-            }
+            return;                                        // (DMA instantiations stage through dma_chunk)
         } else {
             const int c = c0 + xrow;
             const bool cok = c < Ctot;
@@ -451,37 +482,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
     // ---- registers -> LDS (zero fill applied here) ----
     auto store_chunk = [&](int bufoff, int chunk) {
         if constexpr (XVEC) {
-            const int c0 = chunk * CKC;
-            const bool ctail = c0 + CKC > Ctot;              // uniform
-            const int nxv = (deint ? CH : CK) * nvr;
-#pragma unroll
-            for (int i = 0; i < XVIT; ++i) {
-                const int pk = xvo[i];
-                if (i * 256 < nxv && pk < 0) {
-                    const int row = (pk >> 20) & 0x7FF, v4 = pk & 0xFFFFF;
-                    f32x4 v = xv[i];
-                    const int c = c0 + row;
-                    const bool s1 = c >= a.C0;
-                    if (xedge || ctail) {
-                        const int t0 = (s1 ? e01 - a.off1 : e00 - a.off0) + v4;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (c >= Ctot || t0 + k < 0 || t0 + k >= a.Tin) v[k] = 0.f;
-                    }
-                    if (!deint) {
-                        *reinterpret_cast<f32x4*>(Xs + bufoff + row * XP + v4) = v;
-                    } else {
-                        // plane 0 = even samples of the window, plane 1 = odd ones; an odd sub-vector shift swaps
-                        // which half of the vector is which (the residual shift is folded into the read offsets)
-                        const bool odd = ((s1 ? dl1 : dl0) & 1) != 0;
-                        const float2 pe = odd ? make_float2(v[1], v[3]) : make_float2(v[0], v[2]);
-                        const float2 po = odd ? make_float2(v[0], v[2]) : make_float2(v[1], v[3]);
-                        float* xd = Xs + bufoff + row * XP + (v4 >> 1);
-                        *reinterpret_cast<float2*>(xd) = pe;
-                        *reinterpret_cast<float2*>(xd + CH * XP) = po;
-                    }
-                }
-            }
+            (void)chunk;
+            return;
         } else if (!deint) {
             const int lr = tid % TPR;
             float* xd = Xs + bufoff + xrow * XP + lr;
@@ -620,6 +622,130 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
         }
     };
 
+    // ---- s2: MFMA loop over the (channel, tap group) k-steps of one chunk; operands of the next k-step are read right
+    // after the first MFMA of the current one (same interleave as run_taps) ----
+    auto run_s2 = [&](int bufoff, int dlt) __attribute__((always_inline)) {
+        if constexpr (XVEC && !FOLD) {
+            const int ntg = J16 >> 2, nks = CH * ntg;                   // (CH even: nks is even)
+            const float* xa = Xs + bufoff + 2 * (wt0 + li) + lg + dlt;  // channel 0, tap group 0; M tile m at + 32 m
+            const float* wb = Ws + bufoff + lg * WP + wn0 + li;
+            const int wstep = 4 * WP, xwrap = XPR - 4 * (ntg - 1);
+            float a0[MT], b0[NW], a1[MT], b1[NW];
+            auto ldop = [&](float (&av)[MT], float (&bv)[NW]) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) av[m] = xa[32 * m];
+#pragma unroll
+                for (int n = 0; n < NW; ++n) bv[n] = wb[n * 16];
+            };
+            auto mm_first = [&](const float (&av)[MT], const float (&bv)[NW]) { acc[0][0] = mfma16(av[0], bv[0], acc[0][0]); };
+            auto mm_rest = [&](const float (&av)[MT], const float (&bv)[NW]) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NW; ++n)
+                        if (m + n > 0) acc[m][n] = mfma16(av[m], bv[n], acc[m][n]);
+            };
+            auto pin = [&]() {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, MT + NW, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MT * NW - 1, 0);
+            };
+            int tg = 0;
+            auto adv = [&]() {
+                wb += wstep;
+                if (++tg == ntg) { tg = 0; xa += xwrap; } else xa += 4;
+            };
+            ldop(a0, b0);
+            for (int st = 0; st < nks; st += 2) {
+                mm_first(a0, b0);
+                adv();
+                ldop(a1, b1);
+                mm_rest(a0, b0);
+                pin();
+                mm_first(a1, b1);
+                if (st + 2 < nks) adv();
+                ldop(a0, b0);
+                mm_rest(a1, b1);
+                pin();
+            }
+        }
+    };
+
+    // ---- XVEC: chunk -> LDS buffer by DMA.  Wave w issues the KiB blocks {w, w+4, ...} of the X region and of the W
+    // region; every lane supplies the global address of its 16-byte granule (or sits the instruction out) ----
+    auto dma_chunk = [&](int chunk, int bufoff) __attribute__((always_inline)) {
+        if constexpr (XVEC) {
+            const int c0 = chunk * CKC;
+            const bool s1 = c0 >= a.C0;                                  // (a chunk lies in ONE source: launcher rule)
+            const float* xb = s1 ? vb1 + (long long)(c0 - a.C0) * a.pitch1 : vb0 + (long long)c0 * a.pitch0;
+            const int pitch = s1 ? a.pitch1 : a.pitch0, e0s = s1 ? e01 : e00;
+            const int nxg = XROWS * XG;
+#pragma unroll
+            for (int i = 0; i < XDIT; ++i) {
+                if (i * 256 + wave * 64 < nxg) {                         // wave-uniform
+                    const int pk = xdo[i];
+                    int e = e0s + (pk & 0xFFFFF);
+                    e = e < 0 ? 0 : (e > pitch - 4 ? pitch - 4 : e);     // clamped into the row; zeroed later if outside [0, Tin)
+                    if (pk >= 0)
+                        __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(xb + (pk >> 20) * pitch + e),
+                                                         (lds_void_t*)(Xs + bufoff + (i * 256 + wave * 64) * 4), 16, 0, 0);
+                }
+            }
+            const float* wc = a.W + (long long)c0 * (phase2 ? 2 * a.N : a.N);
+            const int nwg = J * CK * WG4;
+#pragma unroll
+            for (int i = 0; i < WDIT; ++i) {
+                if (i * 256 + wave * 64 < nwg) {
+                    const int o = wdo[i];
+                    if (o >= 0)
+                        __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(wc + o),
+                                                         (lds_void_t*)(Ws + bufoff + (i * 256 + wave * 64) * 4), 16, 0, 0);
+                }
+            }
+        }
+    };
+    // edge tiles: zero the staged samples whose time index lies outside [0, Tin)
+    auto zero_fix = [&](int chunk, int bufoff) __attribute__((always_inline)) {
+        if constexpr (XVEC) {
+            const bool s1 = chunk * CKC >= a.C0;
+            const int t00 = (s1 ? e01 - a.off1 : e00 - a.off0);
+            const float inv_xg = 1.0f / (float)XG;
+#pragma unroll
+            for (int i = 0; i < XDIT; ++i) {
+                const int f = tid + i * 256;
+                const int row = fast_div(f, XG, inv_xg), g = f - row * XG;
+                if (row < XROWS && g < nvr) {
+                    const int t0 = t00 + 4 * g;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (t0 + k < 0 || t0 + k >= a.Tin) Xs[bufoff + row * XPR + 4 * g + k] = 0.f;
+                }
+            }
+        }
+    };
+
+    if constexpr (XVEC) {
+        WUN_TRACE_STAMP(7);
+        if (ch_lo < ch_hi && !ab_noload) dma_chunk(ch_lo, 0);
+        WUN_TRACE_STAMP(8);
+        WUN_TRACE_STAMP(9);
+        for (int chunk = ch_lo; chunk < ch_hi; ++chunk) {
+            const int cur = ((chunk - ch_lo) & 1) * LB;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's granules of `chunk` have landed
+            __syncthreads();                                            // ... everybody's have; buffer LB - cur is free
+            if (chunk == ch_lo) { WUN_TRACE_STAMP(1); }
+            if (xedge) {
+                zero_fix(chunk, cur);
+                __syncthreads();
+            }
+            if (chunk + 1 < ch_hi && !ab_noload) dma_chunk(chunk + 1, LB - cur);
+            if (!ab_nomfma) {
+                const int dlt = (chunk * CKC < a.C0) ? dl0 : dl1;
+                if (s2) run_s2(cur, dlt);
+                else run_taps(cur, 0, J, dlt);
+            }
+        }
+    } else {
     // Pipeline: global loads of chunk c+1 are issued before the MFMAs of chunk c; their LDS
     // writes (to the other buffer) sit in the middle of chunk c's MFMA loop, so they issue in
     // the shadow of the matrix pipe; one barrier per chunk.
@@ -641,13 +767,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
         WUN_PRIO_HI();
         if (has_next && !ab_noload) load_chunk(chunk + 1);
         WUN_PRIO_LO();
-        const int dlt = XVEC ? ((chunk * CKC < a.C0) ? dl0 : dl1) : 0;
-        if (!ab_nomfma) run_taps(cur, 0, half, dlt);
+        if (!ab_nomfma) run_taps(cur, 0, half, 0);
         WUN_PRIO_HI();
         if (has_next && !ab_nostore) store_chunk(LB - cur, chunk + 1);
         WUN_PRIO_LO();
-        if (!ab_nomfma) run_taps(cur, half, J, dlt);
+        if (!ab_nomfma) run_taps(cur, half, J, 0);
         if (!ab_nobar) __syncthreads();
+    }
     }
     WUN_TRACE_STAMP(2);
     WUN_PRIO_HI();
@@ -1024,12 +1150,44 @@ long long conv_natural_wgs_phase2(const ConvArgs& a) {
     return (long long)((a.Tout + TT - 1) / TT) * ((a.N + half - 1) / half) * a.B;
 }
 
+static inline int conv_J(const ConvArgs& a);
+// Vector (16-byte) paths need aligned bases / pitches; everything the plan allocates is.
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// may this launch use the DMA-staging instantiation (XVEC) of tile `variant`?
+static int conv_dma_pitch(int width) { return fit_pitch((width + 3) & ~3, 16); }
+static bool conv_xvec_ok(const ConvArgs& a, int variant) {
+    const ConvVariant& cv = kConvVariants[variant];
+    const int Ctot = a.C0 + a.C1;
+    if (cv.fold || cv.CK != 8 || getenv("WUN_NO_DMA") != nullptr) return false;
+    const bool deint = a.loader == LOADER_DEINT;
+    if (deint && ((a.flags & F_PHASE2) || getenv("WUN_DMA_S2") == nullptr)) return false;   // opt-in: per launch +-0, per step 1.7 % slower
+    if (deint && ((a.KW + 3) & ~3) != 2 * ((a.KW + 1) / 2)) return false;   // s2 slab = CK/2 channels x roundup4(KW) taps must equal J * CK rows
+    const int CKC = deint ? cv.CK / 2 : cv.CK;
+    if ((Ctot % CKC) != 0 || (a.C0 % CKC) != 0 || (a.N & 3) != 0 || a.N < 4) return false;       // whole chunks, one source each
+    if (!aligned16(a.src0) || (a.bs0 & 3) != 0 || (a.pitch0 & 3) != 0 || a.pitch0 < 4) return false;
+    if (a.src1 != nullptr && (!aligned16(a.src1) || (a.bs1 & 3) != 0 || (a.pitch1 & 3) != 0 || a.pitch1 < 4)) return false;
+    if (a.off0 < 0 || a.off1 < 0 || !aligned16(a.W)) return false;
+    if ((long long)cv.CK * a.pitch0 >= (1ll << 31) || (long long)cv.CK * a.pitch1 >= (1ll << 31)) return false;
+    return true;
+}
+
 static void conv_geom(const ConvArgs& a, int variant, int& TT, int& NT, int& J, int& XP, int& WP) {
     const ConvVariant& v = kConvVariants[variant];
     TT = v.WT * v.MT * 16;
     NT = v.WN * v.NW * 16;
     J = conv_J(a);
     XP = fit_pitch(v.fold ? WUN_FOLD_XCAP(TT) : TT + J - 1, 16);
+    if (conv_xvec_ok(a, variant)) {
+        if (a.loader == LOADER_DEINT) {
+            // s2: contiguous window of 2 * (TT - 1) + roundup4(KW) samples + the sub-vector shift, row pitch 2 * XP; the
+            // weight slab holds CK / 2 channels x roundup4(KW) taps = J * CK rows only if J * 2 == roundup4(KW)
+            const int span = 2 * (TT - 1) + ((a.KW + 3) & ~3) + 3;
+            XP = ((((span + 3) & ~3) + 7) / 8) * 4;
+        } else {
+            XP = conv_dma_pitch(TT + J - 1 + 3);                             // whole 16-byte granules incl. the sub-vector shift
+        }
+    }
     WP = fit_pitch(NT, 16);
 }
 
@@ -1072,28 +1230,6 @@ void conv_splitk(const ConvArgs& a, int variant, long long part_cap_floats, int&
     cps = (int)((nchunks + want - 1) / want);
     ksplit = (nchunks + cps - 1) / cps;
     if (ksplit < 2) { ksplit = 1; cps = nchunks; }
-}
-
-// Vector (16-byte) paths need aligned bases / pitches; everything the plan allocates is.
-static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-
-// may this launch use the vector-staging instantiation (XVEC) of tile `variant`?
-static bool conv_xvec_ok(const ConvArgs& a, int variant) {
-    const ConvVariant& cv = kConvVariants[variant];
-    const int Ctot = a.C0 + a.C1;
-    if (cv.fold || Ctot <= 4 || cv.CK != 8 || getenv("WUN_XVEC") == nullptr) return false;   // opt-in: measured 2.7 % SLOWER per step
-    if (!aligned16(a.src0) || (a.bs0 & 3) != 0 || (a.pitch0 & 3) != 0) return false;
-    if (a.src1 != nullptr && (!aligned16(a.src1) || (a.bs1 & 3) != 0 || (a.pitch1 & 3) != 0)) return false;
-    if (a.off0 < 0 || a.off1 < 0) return false;
-    const bool deint = a.loader == LOADER_DEINT;
-    const int CKC = deint ? cv.CK / 2 : cv.CK;
-    const int dl0 = (((a.off0 - a.shift) % 4) + 4) % 4, dl1 = a.C1 > 0 ? (((a.off1 - a.shift) % 4) + 4) % 4 : dl0;
-    if (a.C1 > 0 && dl0 != dl1 && (a.C0 % CKC) != 0) return false;      // a chunk would mix two sub-vector shifts
-    int TT, NT, J, XP, WP;
-    conv_geom(a, variant, TT, NT, J, XP, WP);
-    const int span = deint ? 2 * (TT + J - 1) : TT + J - 1;
-    const int nvr = (span + (dl0 > dl1 ? dl0 : dl1) + 3) / 4;
-    return (deint ? 2 * nvr : 4 * nvr) <= XP;                             // the vectors of a row stay inside its LDS pitch
 }
 
 template <int MT, int NW, int WT, int WN, int CK, bool VECW, bool FOLD = false, bool XVEC = false>
@@ -1143,7 +1279,7 @@ static hipError_t conv_launch_t(ConvArgs a, int variant, float* part, long long 
     if (grid <= 0) return hipSuccess;
     char nm[64];
     snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %s%s%s>", MT, NW, WT, WN, CK, VECW ? "true" : "false",
-             FOLD ? ", fold" : "", XVEC ? ", xvec" : "");
+             FOLD ? ", fold" : "", XVEC ? ", dma" : "");
     {
         char tag[160];
         snprintf(tag, sizeof(tag), "C=%d N=%d T=%d K=%d ld=%d B=%d ks=%d ph2=%d acc=%d os=%d grid=%lld", a.C0 + a.C1, a.N,

@@ -595,6 +595,38 @@ static float time_launch(const wun_plan* p, hipStream_t s, const std::function<h
     return best;
 }
 
+// One event-bracketed run (no warm-up); 1e30 on failure.
+static float time_once(const wun_plan* p, hipStream_t s, const std::function<hipError_t()>& fn) {
+    (void)hipEventRecord(p->tev0, s);
+    if (fn() != hipSuccess) { (void)hipGetLastError(); return 1e30f; }
+    (void)hipEventRecord(p->tev1, s);
+    if (hipEventSynchronize(p->tev1) != hipSuccess) return 1e30f;
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, p->tev0, p->tev1);
+    return ms;
+}
+
+// Times `n` candidate launches of ONE launch position against each other: every candidate is warmed up once, then
+// the candidates are run round-robin for WUN_TUNE_ROUNDS rounds (default 4) and each keeps its fastest run.  The shader
+// clock of a busy MI355X drifts by ~10 % over milliseconds (DVFS); timing candidates one after the other in a single
+// pass -- the round-1/2 tuner -- lets that drift decide between tiles that differ by a few per cent.  best[i] = 1e30 for
+// candidates that failed.
+static void time_candidates(const wun_plan* p, hipStream_t s, int n, const std::function<hipError_t(int)>& launch, float* best) {
+    static const int rounds = getenv("WUN_TUNE_ROUNDS") ? std::max(1, atoi(getenv("WUN_TUNE_ROUNDS"))) : 4;
+    for (int i = 0; i < n; ++i) {
+        best[i] = 1e30f;
+        if (launch(i) != hipSuccess) { (void)hipGetLastError(); best[i] = -1.f; }    // warm-up / validity
+    }
+    for (int r = 0; r < rounds; ++r)
+        for (int i = 0; i < n; ++i) {
+            if (best[i] < 0.f) continue;
+            const float ms = time_once(p, s, [&]() { return launch(i); });
+            if (ms < best[i]) best[i] = ms;
+        }
+    for (int i = 0; i < n; ++i)
+        if (best[i] < 0.f) best[i] = 1e30f;
+}
+
 // at < 0: the launch takes the next position of the step's launch order; at >= 0: a position reserved earlier
 // (deferred launches keep the position they have in the canonical order, so tuned tables stay aligned)
 static hipError_t conv_dispatch(const wun_plan* p, ConvArgs a, float* part, long long cap, hipStream_t s, long long at = -1) {
@@ -634,18 +666,22 @@ static hipError_t conv_dispatch(const wun_plan* p, ConvArgs a, float* part, long
     }
     if (p->tune_mode == 1) {
         if (vec.size() <= idx) vec.resize(idx + 1, ConvChoice{-1, 0});
-        ConvChoice cands[640];
+        static ConvChoice cands[640];
+        static float tms[641];
         const int n = conv_list_candidates(a, part ? cap : 0, cands, 640);
-        // the heuristic choice is the baseline; a candidate has to beat it by > 2 %
-        float best = time_launch(p, s, [&]() { return launch_conv(a, part, cap, s); });
-        const float base = best;
-        ConvChoice bc{-1, 0};
-        for (int i = 0; i < n; ++i) {
+        // candidate n = the heuristic choice (the baseline); a candidate has to beat it by > 2 %
+        time_candidates(p, s, n + 1, [&](int i) {
             ConvArgs b = a;
-            b.force_variant = cands[i].variant + 1; b.force_ksplit = cands[i].ksplit;
-            const float ms = time_launch(p, s, [&]() { return launch_conv(b, part, cap, s); });
-            if (ms < best * 0.98f) { best = ms; bc = cands[i]; }
-        }
+            if (i < n) { b.force_variant = cands[i].variant + 1; b.force_ksplit = cands[i].ksplit; }
+            return launch_conv(b, part, cap, s);
+        }, tms);
+        const float base = tms[n];
+        float best = base;
+        ConvChoice bc{-1, 0};
+        int bi = -1;
+        for (int i = 0; i < n; ++i)
+            if (bi < 0 ? tms[i] < 1e29f : tms[i] < tms[bi]) bi = i;
+        if (bi >= 0 && tms[bi] < base * 0.98f) { best = tms[bi]; bc = cands[bi]; }
         vec[idx] = bc;
         if (getenv("WUN_TUNE_LOG"))
             fprintf(stderr, "[tune conv %s#%zu] C=%d N=%d T=%d K=%d ld=%d ph2=%d cands=%d base %.3f ms -> v=%d ks=%d %.3f ms\n",
@@ -876,10 +912,11 @@ static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const Conv
 
     if (p->tune_mode == 1) {
         if (p->wg_bwd.size() <= idx) p->wg_bwd.resize(idx + 1, WgradChoice{0, 0, {0, 0}});
-        // candidates: shared geometry x per-part split counts, timed with the split reduction
-        float best = time_launch(p, s, [&]() { return run(parts); });
-        const float base = best;
-        WgradChoice bc{0, 0, {0, 0}};
+        // candidates: shared geometry x per-part split counts, timed with the split reduction (round-robin, see
+        // time_candidates); candidate 0 = the heuristic choice
+        struct Cand { WgradArgs g[2]; WgradChoice c; };
+        std::vector<Cand> cv;
+        { Cand c0; for (int i = 0; i < nparts; ++i) c0.g[i] = parts[i]; c0.c = WgradChoice{0, 0, {0, 0}}; cv.push_back(c0); }
         static const int mtws[] = {8, 6, 4, 2, 1};         // (8: bf16 kernel only; 6, 2, 1: exact-fp32 kernel only)
         WgradArgs g[2];
         for (int mi = 0; mi < 5; ++mi)
@@ -903,10 +940,21 @@ static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const Conv
                         g[i].nsplit = ns;
                     }
                     if (same) continue;
-                    const float ms = time_launch(p, s, [&]() { return run(g); });
-                    if (ms < best * 0.98f) { best = ms; bc = WgradChoice{mtws[mi], nw, {g[0].nsplit, nparts > 1 ? g[1].nsplit : 0}}; }
+                    Cand c;
+                    for (int i = 0; i < nparts; ++i) c.g[i] = g[i];
+                    c.c = WgradChoice{mtws[mi], nw, {g[0].nsplit, nparts > 1 ? g[1].nsplit : 0}};
+                    cv.push_back(c);
                 }
             }
+        std::vector<float> tms(cv.size());
+        time_candidates(p, s, (int)cv.size(), [&](int i) { return run(cv[(size_t)i].g); }, tms.data());
+        const float base = tms[0];
+        float best = base;
+        WgradChoice bc{0, 0, {0, 0}};
+        size_t bi = 0;
+        for (size_t i = 1; i < cv.size(); ++i)
+            if (tms[i] < tms[bi]) bi = i;
+        if (bi > 0 && tms[bi] < base * 0.98f) { best = tms[bi]; bc = cv[bi].c; }
         p->wg_bwd[idx] = bc;
         if (getenv("WUN_TUNE_LOG"))
             fprintf(stderr, "[tune wgrad #%zu] C=%d N=%d T=%d K=%d ld=%d parts=%d base(ns=%d) %.3f ms -> mtw=%d nw=%d ns=%d,%d %.3f ms\n",
