@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
 #define WUN_PRIO_HI() do { if (stprio) __builtin_amdgcn_s_setprio(2); } while (0)
 #define WUN_PRIO_LO() do { if (stprio) __builtin_amdgcn_s_setprio(0); } while (0)
     WUN_PRIO_HI();
-#elif defined(WUN_STAGE_PRIO)
+#elif !defined(WUN_NO_STAGE_PRIO)   /* raised wave priority for prologue / staging / epilogue code: same-box A/B 8.90 -> 8.87 ms per step */
 #define WUN_PRIO_HI() __builtin_amdgcn_s_setprio(2)
 #define WUN_PRIO_LO() __builtin_amdgcn_s_setprio(0)
     WUN_PRIO_HI();
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
             const int cur = ((chunk - ch_lo) & 1) * LB;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's granules of `chunk` have landed
             __syncthreads();                                            // ... everybody's have; buffer LB - cur is free
-            if (chunk == ch_lo) { WUN_TRACE_STAMP(1); }
+            if (chunk == ch_lo) { WUN_TRACE_STAMP(1); WUN_PRIO_LO(); }
             if (xedge) {
                 zero_fix(chunk, cur);
                 __syncthreads();

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -683,6 +684,19 @@ static hipError_t conv_dispatch(const wun_plan* p, ConvArgs a, float* part, long
             if (bi < 0 ? tms[i] < 1e29f : tms[i] < tms[bi]) bi = i;
         if (bi >= 0 && tms[bi] < base * 0.98f) { best = tms[bi]; bc = cands[bi]; }
         vec[idx] = bc;
+        if (const char* af = getenv("WUN_TUNE_ALTS")) {
+            // near-best candidates of this position (isolated timing) for the whole-step tuner, tools/step_tune.py
+            if (FILE* f = fopen(af, "a")) {
+                const float lim = std::min(best, base) * 1.15f;
+                fprintf(f, "%s %zu %d %d %.4f\n", p->in_bwd ? "cb" : "cf", idx, -1, 0, base);
+                std::vector<int> order;
+                for (int i = 0; i < n; ++i) if (tms[i] <= lim) order.push_back(i);
+                std::sort(order.begin(), order.end(), [&](int x, int y) { return tms[x] < tms[y]; });
+                for (size_t k = 0; k < order.size() && k < 6; ++k)
+                    fprintf(f, "%s %zu %d %d %.4f\n", p->in_bwd ? "cb" : "cf", idx, cands[order[k]].variant, cands[order[k]].ksplit, tms[order[k]]);
+                fclose(f);
+            }
+        }
         if (getenv("WUN_TUNE_LOG"))
             fprintf(stderr, "[tune conv %s#%zu] C=%d N=%d T=%d K=%d ld=%d ph2=%d cands=%d base %.3f ms -> v=%d ks=%d %.3f ms\n",
                     p->in_bwd ? "bwd" : "fwd", idx, a.C0 + a.C1, a.N, a.Tout, a.KW, a.loader, (a.flags & F_PHASE2) ? 1 : 0, n,
@@ -955,6 +969,19 @@ static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const Conv
         for (size_t i = 1; i < cv.size(); ++i)
             if (tms[i] < tms[bi]) bi = i;
         if (bi > 0 && tms[bi] < base * 0.98f) { best = tms[bi]; bc = cv[bi].c; }
+        if (const char* af = getenv("WUN_TUNE_ALTS")) {
+            if (FILE* f = fopen(af, "a")) {
+                const float lim = std::min(best, base) * 1.15f;
+                std::vector<size_t> order;
+                for (size_t i = 0; i < cv.size(); ++i) if (tms[i] <= lim) order.push_back(i);
+                std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return tms[x] < tms[y]; });
+                for (size_t k = 0; k < order.size() && k < 6; ++k) {
+                    const WgradChoice& c = cv[order[k]].c;
+                    fprintf(f, "wg %zu %d %d %d %d %.4f\n", idx, c.mtw, c.nw, c.nsplit[0], c.nsplit[1], tms[order[k]]);
+                }
+                fclose(f);
+            }
+        }
         p->wg_bwd[idx] = bc;
         if (getenv("WUN_TUNE_LOG"))
             fprintf(stderr, "[tune wgrad #%zu] C=%d N=%d T=%d K=%d ld=%d parts=%d base(ns=%d) %.3f ms -> mtw=%d nw=%d ns=%d,%d %.3f ms\n",
