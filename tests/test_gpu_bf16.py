@@ -35,6 +35,9 @@ BF16_OUT_TOL = 1e-2      # network outputs vs the float64 oracle, absolute (outp
 BF16_LOSS_TOL = 1e-2     # relative; observed <= 1.6e-3
 BF16_GRAD_TOL = 2.5e-1   # x max|g| per gradient tensor (small nets: few terms average the operand rounding out;
                          # observed <= 1.7e-1 on the 8-filter test nets, <= 6e-2 at full size)
+BF16_INTERP_L2_TOL = 4.5e-1   # bias / interp vectors, relative L2; observed <= 0.15 (3x)
+BF16_GRAD_L2_TOL = 1.1e-1  # per gradient tensor ||g - g_ref||_2 / ||g_ref||_2: the sharper norm for rounding noise (a wrong tap
+                         # or a dropped channel group of a narrow layer moves it by O(1/sqrt(taps)) ~ 0.3+); observed <= 3.6e-2 on conv kernels (3x)
 
 
 @pytest.fixture(scope="module")
@@ -234,15 +237,26 @@ def _step(cfg_over, ocfg, params, B, frames, seed, tag, tune=False):
     el = abs(loss.item() - oloss) / max(abs(oloss), 1e-3)
     record("bf16_loss_vs_float64_oracle", tag, el, BF16_LOSS_TOL)
     g = sep.gradients()
-    worst = (0.0, "")
+    worst, worst_l2, worst_interp = (0.0, ""), (0.0, ""), 0.0
     for (n, _), og in zip(params, ograds):
         got = g[n].cpu().double()
         assert torch.isfinite(got).all(), n
         rel = (got - og).abs().max().item() / max(og.abs().max().item(), 1e-30)
         if rel > worst[0]:
             worst = (rel, n)
+        l2 = (got - og).norm().item() / max(og.norm().item(), 1e-30)
+        if not n.endswith("/kernel"):
+            # bias / learned-interpolation vectors: a handful of elements, each the difference of long sums of
+            # bf16-rounded products (heavy cancellation): looser, recorded separately
+            worst_interp = max(worst_interp, l2)
+        elif l2 > worst_l2[0]:
+            worst_l2 = (l2, n)
     record("bf16_gradients_vs_float64_oracle", "%s (worst: %s)" % (tag, worst[1]), worst[0], BF16_GRAD_TOL)
+    record("bf16_gradients_rel_l2_vs_float64_oracle", "%s (worst: %s)" % (tag, worst_l2[1]), worst_l2[0], BF16_GRAD_L2_TOL)
     assert eo <= BF16_OUT_TOL and el <= BF16_LOSS_TOL and worst[0] <= BF16_GRAD_TOL, (eo, el, worst)
+    record("bf16_vector_gradients_rel_l2_vs_float64_oracle", tag, worst_interp, BF16_INTERP_L2_TOL)
+    assert worst_l2[0] <= BF16_GRAD_L2_TOL, worst_l2
+    assert worst_interp <= BF16_INTERP_L2_TOL, worst_interp
     return sep
 
 

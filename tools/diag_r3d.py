@@ -8,16 +8,17 @@ lib = _lib.load()
 lib.wun_dbg_trace_read.restype = C.c_int; lib.wun_dbg_trace_read.argtypes = [C.c_void_p, C.c_int, C.c_int]
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 B = 16
-LAYERS = [("up9_168_72_k5", "fwd", 168, 72, 5, 4108, 1, 18), ("win3_72_96_k15", "fwd", 72, 96, 15, 2076, 1, 18), ("dgrad_s2_96_120", "dgrad", 96, 120, 15, 9205, 2, -1)]
+LAYERS = [("down3_s2_72_96", "fwd", 72, 96, 15, 18420, 2, 18), ("down4_s2_96_120", "fwd", 96, 120, 15, 9204, 2, 24)]
 
 def make(kind, cin, cout, k, t, stride):
     t_out = (t - k) // stride + 1
     x = torch.rand(B, cin, t, device="cuda") * 2 - 1
     w = (torch.rand(k, cin, cout, device="cuda") * 2 - 1) / (k * cin) ** 0.5
-    b = torch.zeros(cout, device="cuda"); y = torch.empty(B, cout, t_out, device="cuda")
+    t_y = (t_out + 3) // 4 * 4
+    b = torch.zeros(cout, device="cuda"); y = torch.empty(B, cout, t_y, device="cuda")
     dz = torch.rand(B, cout, t_out, device="cuda") * 2 - 1
     if kind == "fwd":
-        fn = lambda: lib.wun_op_conv1d(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), B, cin, cout, k, t, t_out, stride, 0, 1, st)
+        fn = lambda: lib.wun_op_conv1d_ex(x.data_ptr(), cin, None, 0, w.data_ptr(), b.data_ptr(), y.data_ptr(), None, B, cout, k, t, t_out, t_y, stride, 0, 1, 0, 1, 0, st)
     else:
         wts = torch.empty(2 * (k + 1) * cin * cout + 64, device="cuda"); dx = torch.empty(B, cin, t, device="cuda")
         fn = lambda: lib.wun_op_conv1d_dgrad(dz.data_ptr(), w.data_ptr(), dx.data_ptr(), wts.data_ptr(), B, cin, cout, k, t, t_out, stride, 0, st)

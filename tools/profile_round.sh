@@ -6,12 +6,12 @@ set -u
 tag=${1:-round}
 R=$PWD
 mkdir -p gpurun_out
-# tilings: the committed pinned table if it matches this build (PINNED=1, default), else a fresh one
-export WUN_TUNE_CACHE=$R/gpurun_out/${tag}_tune_table.txt
-if [ "${PINNED:-1}" = 1 ] && [ -f $R/profiles/round2_tune_table.txt ]; then
-    cp $R/profiles/round2_tune_table.txt $WUN_TUNE_CACHE
-else
+# tilings: bench.py imports the committed pinned table of the config by itself (read-only); PINNED=0 -> fresh tuning
+PIN=$R/profiles/round3_tune_table.txt
+if [ "${PINNED:-1}" != 1 ]; then
+    export WUN_TUNE_CACHE=$R/gpurun_out/${tag}_tune_table.txt
     [ "${KEEP_TUNE:-0}" = 1 ] || rm -f $WUN_TUNE_CACHE
+    PIN=$WUN_TUNE_CACHE
 fi
 if [ "${ONLYCFGS:-0}" != 1 ]; then
 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
@@ -20,6 +20,8 @@ rm -rf /tmp/prof_${tag}
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${tag} -o ks -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline \
     > $R/gpurun_out/${tag}_prof_bench.json 2> $R/gpurun_out/${tag}_prof_bench.err
 cp $(find /tmp/prof_${tag} -name "*kernel_stats.csv" | head -1) $R/gpurun_out/${tag}_kernel_stats.csv
+cp $(find /tmp/prof_${tag} -name "*kernel_trace.csv" | head -1) $R/gpurun_out/${tag}_kernel_trace.csv
+python $R/tools/timeline.py $R/gpurun_out/${tag}_kernel_trace.csv 2 $R/gpurun_out/${tag}_timeline.txt
 # same command with every launch on one stream: per-kernel durations free of overlap with the other
 # streams' kernels -- the figure bench.py's roofline (HIP events, single-stream profiled steps) must agree with
 rm -rf /tmp/prof1_${tag}
@@ -37,7 +39,7 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_A
 python $R/tools/pmc_summarize.py $(find /tmp/pmc_mfma -name "*counter_collection.csv" | head -1) $R/gpurun_out/${tag}_pmc_mfma.json
 cd $R
 python tools/pmc_report.py gpurun_out/${tag}_pmc_FETCH_SIZE.json gpurun_out/${tag}_pmc_WRITE_SIZE.json gpurun_out/${tag}_pmc_mfma.json \
-    gpurun_out/${tag}_pmc_traffic.json gpurun_out/${tag}_pmc_mfma_util.txt "$tag" $WUN_TUNE_CACHE
+    gpurun_out/${tag}_pmc_traffic.json gpurun_out/${tag}_pmc_mfma_util.txt "$tag" $PIN
 tail -1 gpurun_out/${tag}_bench.json | cut -c1-400
 fi
 cd $R

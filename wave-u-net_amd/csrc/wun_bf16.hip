@@ -525,6 +525,9 @@ bool conv_bf16_choice_ok(const ConvArgs& a, int variant) {
     const int chan = phase2 ? NT / 2 : NT;
     const int padded = (a.N + chan - 1) / chan * chan;
     if (padded * 3 > a.N * 4 + 48) return false;                       // > ~33 % padded columns
+    // the packed weight image is padded to a multiple of 64 columns: a tile whose last column group runs past that
+    // would DMA the next channel group's rows (results land in discarded columns, but it is an out-of-image read)
+    if (!phase2 && padded > (a.N + 63) / 64 * 64) return false;
     if (TT > 64 && TT >= 2 * a.Tout) return false;                     // mostly padding in time
     if (nck > (a.C0 + a.C1 + 31) / 32) return false;
     const int planes = a.loader == LOADER_DEINT ? 2 : 1;
