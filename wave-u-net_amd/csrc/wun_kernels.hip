@@ -325,19 +325,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
     bool xedge = false;
     const float* vb0 = a.src0 + (long long)b_ld * a.bs0;                 // row bases WITHOUT the crop offset (aligned)
     const float* vb1 = (a.src1 != nullptr) ? a.src1 + (long long)b_ld * a.bs1 : vb0;
-    // Stride-2 loader of the DMA instantiations ("s2"): the window stays CONTIGUOUS in LDS (row = one input channel,
-    // pitch 2 * XP) and the four k lanes of an MFMA are four consecutive TAPS of that channel: lane (i, k) reads
-    // x[2 * (t0 + i) + 4 * tg + k] -- banks 2i + k, conflict-free -- against the weight rows (ch, 4 * tg + k) of a slab
-    // laid out [channel][tap rounded up to 4][WP]; the taps past KW are zero rows written once at kernel start.
-    const bool s2 = XVEC && deint;
-    const int J16 = (a.KW + 3) & ~3;                                     // s2: taps per channel in LDS
-    const int XPR = s2 ? 2 * XP : XP;                                    // LDS row pitch of the input window
-    const int XROWS = s2 ? CH : CK;
-    const int XG = XPR >> 2, WG4 = WP >> 2;                              // granules per LDS row
+    const int XG = XP >> 2, WG4 = WP >> 2;                               // granules per LDS row
     if constexpr (XVEC) {
-        const int tbase = (s2 ? 2 * q0_ld : q0_ld) - a.shift;
-        const int span = s2 ? 2 * (TT - 1) + J16 : UW;
-        nvr = (span + (dl0 > dl1 ? dl0 : dl1) + 3) >> 2;
+        const int tbase = q0_ld - a.shift;
+        nvr = (UW + (dl0 > dl1 ? dl0 : dl1) + 3) >> 2;
         e00 = a.off0 + tbase - dl0;
         e01 = a.off1 + tbase - dl1;
         const int tf0 = tbase - dl0, tf1 = tbase - dl1;                  // time of the first staged element
@@ -347,17 +338,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
         for (int i = 0; i < XDIT; ++i) {
             const int f = tid + i * 256;
             const int row = fast_div(f, XG, inv_xg), g = f - row * XG;
-            xdo[i] = (row < XROWS && g < nvr) ? (row << 20) | (4 * g) : -1;
+            xdo[i] = (row < CK && g < nvr) ? (row << 20) | (4 * g) : -1;
         }
         const float inv_wg = 1.0f / (float)WG4;
 #pragma unroll
         for (int i = 0; i < WDIT; ++i) {
             const int f = tid + i * 256;
             const int row = fast_div(f, WG4, inv_wg), c4 = f - row * WG4;
-            int j, r;
-            bool ok;
-            if (s2) { r = row / J16; j = row - r * J16; ok = r < CH && j < a.KW && c4 < NT4; }
-            else { j = row / CK; r = row - j * CK; ok = j < J && c4 < NT4; }
+            const int j = row / CK, r = row - j * CK;
+            const bool ok = j < J && c4 < NT4;
             int wo;
             if (!phase2) {
                 int col = n0 + c4 * 4;
@@ -370,16 +359,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
                 wo = (j * Ctot + r) * (2 * a.N) + ph * a.N + col;
             }
             wdo[i] = ok ? wo : -1;
-        }
-        if (s2 && J16 != a.KW) {
-            // zero rows of the taps [KW, J16) in both LDS buffers (never overwritten: their DMA lanes are idle)
-            const int nz = CH * (J16 - a.KW) * NT;
-            for (int f = tid; f < 2 * nz; f += 256) {
-                const int bsel = f >= nz ? 1 : 0, ff = f - bsel * nz;
-                const int col = ff % NT, rr = ff / NT;
-                const int r = rr / (J16 - a.KW), j = a.KW + rr % (J16 - a.KW);
-                Ws[bsel * LB + (r * J16 + j) * WP + col] = 0.f;
-            }
         }
     }
     if constexpr (!XVEC) {
@@ -622,55 +601,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
         }
     };
 
-    // ---- s2: MFMA loop over the (channel, tap group) k-steps of one chunk; operands of the next k-step are read right
-    // after the first MFMA of the current one (same interleave as run_taps) ----
-    auto run_s2 = [&](int bufoff, int dlt) __attribute__((always_inline)) {
-        if constexpr (XVEC && !FOLD) {
-            const int ntg = J16 >> 2, nks = CH * ntg;                   // (CH even: nks is even)
-            const float* xa = Xs + bufoff + 2 * (wt0 + li) + lg + dlt;  // channel 0, tap group 0; M tile m at + 32 m
-            const float* wb = Ws + bufoff + lg * WP + wn0 + li;
-            const int wstep = 4 * WP, xwrap = XPR - 4 * (ntg - 1);
-            float a0[MT], b0[NW], a1[MT], b1[NW];
-            auto ldop = [&](float (&av)[MT], float (&bv)[NW]) {
-#pragma unroll
-                for (int m = 0; m < MT; ++m) av[m] = xa[32 * m];
-#pragma unroll
-                for (int n = 0; n < NW; ++n) bv[n] = wb[n * 16];
-            };
-            auto mm_first = [&](const float (&av)[MT], const float (&bv)[NW]) { acc[0][0] = mfma16(av[0], bv[0], acc[0][0]); };
-            auto mm_rest = [&](const float (&av)[MT], const float (&bv)[NW]) {
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int n = 0; n < NW; ++n)
-                        if (m + n > 0) acc[m][n] = mfma16(av[m], bv[n], acc[m][n]);
-            };
-            auto pin = [&]() {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, MT + NW, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, MT * NW - 1, 0);
-            };
-            int tg = 0;
-            auto adv = [&]() {
-                wb += wstep;
-                if (++tg == ntg) { tg = 0; xa += xwrap; } else xa += 4;
-            };
-            ldop(a0, b0);
-            for (int st = 0; st < nks; st += 2) {
-                mm_first(a0, b0);
-                adv();
-                ldop(a1, b1);
-                mm_rest(a0, b0);
-                pin();
-                mm_first(a1, b1);
-                if (st + 2 < nks) adv();
-                ldop(a0, b0);
-                mm_rest(a1, b1);
-                pin();
-            }
-        }
-    };
-
     // ---- XVEC: chunk -> LDS buffer by DMA.  Wave w issues the KiB blocks {w, w+4, ...} of the X region and of the W
     // region; every lane supplies the global address of its 16-byte granule (or sits the instruction out) ----
     auto dma_chunk = [&](int chunk, int bufoff) __attribute__((always_inline)) {
@@ -679,7 +609,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
             const bool s1 = c0 >= a.C0;                                  // (a chunk lies in ONE source: launcher rule)
             const float* xb = s1 ? vb1 + (long long)(c0 - a.C0) * a.pitch1 : vb0 + (long long)c0 * a.pitch0;
             const int pitch = s1 ? a.pitch1 : a.pitch0, e0s = s1 ? e01 : e00;
-            const int nxg = XROWS * XG;
+            const int nxg = CK * XG;
 #pragma unroll
             for (int i = 0; i < XDIT; ++i) {
                 if (i * 256 + wave * 64 < nxg) {                         // wave-uniform
@@ -714,11 +644,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
             for (int i = 0; i < XDIT; ++i) {
                 const int f = tid + i * 256;
                 const int row = fast_div(f, XG, inv_xg), g = f - row * XG;
-                if (row < XROWS && g < nvr) {
+                if (row < CK && g < nvr) {
                     const int t0 = t00 + 4 * g;
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        if (t0 + k < 0 || t0 + k >= a.Tin) Xs[bufoff + row * XPR + 4 * g + k] = 0.f;
+                        if (t0 + k < 0 || t0 + k >= a.Tin) Xs[bufoff + row * XP + 4 * g + k] = 0.f;
                 }
             }
         }
@@ -739,11 +669,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
                 __syncthreads();
             }
             if (chunk + 1 < ch_hi && !ab_noload) dma_chunk(chunk + 1, LB - cur);
-            if (!ab_nomfma) {
-                const int dlt = (chunk * CKC < a.C0) ? dl0 : dl1;
-                if (s2) run_s2(cur, dlt);
-                else run_taps(cur, 0, J, dlt);
-            }
+            if (!ab_nomfma) run_taps(cur, 0, J, (chunk * CKC < a.C0) ? dl0 : dl1);
         }
     } else {
     // Pipeline: global loads of chunk c+1 are issued before the MFMAs of chunk c; their LDS
@@ -1160,10 +1086,10 @@ static bool conv_xvec_ok(const ConvArgs& a, int variant) {
     const ConvVariant& cv = kConvVariants[variant];
     const int Ctot = a.C0 + a.C1;
     if (cv.fold || cv.CK != 8 || getenv("WUN_NO_DMA") != nullptr) return false;
-    const bool deint = a.loader == LOADER_DEINT;
-    if (deint && ((a.flags & F_PHASE2) || getenv("WUN_DMA_S2") == nullptr)) return false;   // opt-in: per launch +-0, per step 1.7 % slower
-    if (deint && ((a.KW + 3) & ~3) != 2 * ((a.KW + 1) / 2)) return false;   // s2 slab = CK/2 channels x roundup4(KW) taps must equal J * CK rows
-    const int CKC = deint ? cv.CK / 2 : cv.CK;
+    // (a stride-2 variant -- contiguous window, the four k lanes = four consecutive taps -- was built and measured in
+    //  round 3: its chunk loop is 14 % faster but the step 1 % slower; not in the tree)
+    if (a.loader != LOADER_DIRECT) return false;
+    const int CKC = cv.CK;
     if ((Ctot % CKC) != 0 || (a.C0 % CKC) != 0 || (a.N & 3) != 0 || a.N < 4) return false;       // whole chunks, one source each
     if (!aligned16(a.src0) || (a.bs0 & 3) != 0 || (a.pitch0 & 3) != 0 || a.pitch0 < 4) return false;
     if (a.src1 != nullptr && (!aligned16(a.src1) || (a.bs1 & 3) != 0 || (a.pitch1 & 3) != 0 || a.pitch1 < 4)) return false;
@@ -1178,16 +1104,7 @@ static void conv_geom(const ConvArgs& a, int variant, int& TT, int& NT, int& J, 
     NT = v.WN * v.NW * 16;
     J = conv_J(a);
     XP = fit_pitch(v.fold ? WUN_FOLD_XCAP(TT) : TT + J - 1, 16);
-    if (conv_xvec_ok(a, variant)) {
-        if (a.loader == LOADER_DEINT) {
-            // s2: contiguous window of 2 * (TT - 1) + roundup4(KW) samples + the sub-vector shift, row pitch 2 * XP; the
-            // weight slab holds CK / 2 channels x roundup4(KW) taps = J * CK rows only if J * 2 == roundup4(KW)
-            const int span = 2 * (TT - 1) + ((a.KW + 3) & ~3) + 3;
-            XP = ((((span + 3) & ~3) + 7) / 8) * 4;
-        } else {
-            XP = conv_dma_pitch(TT + J - 1 + 3);                             // whole 16-byte granules incl. the sub-vector shift
-        }
-    }
+    if (conv_xvec_ok(a, variant)) XP = conv_dma_pitch(TT + J - 1 + 3);       // whole 16-byte granules incl. the sub-vector shift
     WP = fit_pitch(NT, 16);
 }
 
@@ -1451,6 +1368,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a, int nMG
     const int lane = tid & 63;
     const int li = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef WUN_ABLATION
+    const bool tr_on = (a.ablate & 64) && tid == 0 && blockIdx.x < WUN_TRACE_WGS;      // workgroup trace, tools/diag_r3g.py
+    unsigned long long* trp = g_wun_trace + (size_t)(blockIdx.x < WUN_TRACE_WGS ? blockIdx.x : 0) * 16;
+    if (tr_on) {
+        trp[0] = __builtin_readcyclecounter();
+        trp[5] = wall_clock64();
+        trp[4] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                 ((unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15) << 32);
+    }
+#endif
     int bid = xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x);
     const int ng = bid % nNG; bid /= nNG;
     const int mg = bid % nMG;
@@ -1620,7 +1547,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a, int nMG
 #else
     constexpr bool wb_noload = false, wb_nostore = false, wb_nomfma = false, wb_noepi = false;
 #endif
+    WUN_TRACE_STAMP(7);
     if (u0 < u1 && !wb_noload) load_unit(u0);
+    WUN_TRACE_STAMP(1);
     for (int u = u0; u < u1; ++u) {
         const int qt = u % a.nQT;
         int nq = a.Tq - qt * TK; if (nq > TK) nq = TK;
@@ -1685,6 +1614,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a, int nMG
         }
     }
 
+    WUN_TRACE_STAMP(2);
     if (wb_noepi && acc[0][0][0] != 12345.678f) return;
     if (!a.direct) {
         // split partial, tile-major: each wave stores its accumulator tiles as contiguous 1 KiB
@@ -1698,6 +1628,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a, int nMG
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
             for (int n = 0; n < NW; ++n) tile[(mt * NW + n) * 64] = acc[mt][n];
+        WUN_TRACE_END();
         return;
     }
     // single split: final layout directly (weights [K][Cin][Cout], then the bias row)

@@ -1100,10 +1100,20 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
     // window of dz_dec[i-1], and the row-wide conv later ADDS inside the window (ConvArgs.acc_lo / acc_len) and stores
     // outside it: a + b == b + a, results are bit-identical to the old order.  Queued here, issued by the next flush
     // (whose event already orders the side streams behind the producing kernels: no extra packet on the chain).
-    // Measured (round 3, same-box A/B, tuned tables per arm): 8.98 vs 8.99 ms per step -- the step is bound by the aggregate
-    // throughput of the MFMA kernels, not by the length of the chain, so moving 0.46 ms of work off the chain buys nothing.
-    // Kept as an option (WUN_EARLY_WINDOW=1; changes the launch order, i.e. needs its own tuning table).
-    const bool early_win = !same && !p->bf16 && getenv("WUN_EARLY_WINDOW") != nullptr;
+    // Default "deep": only the deep levels (input gradient = separate phase launches on a launch-latency-bound chain):
+    // same-box A/B 8.84 -> 8.82 ms.  "all" additionally moves the FLOP-heavy levels' window parts (8.98 vs 8.99: the
+    // end of the backward pass is throughput-bound, not chain-bound); "0" restores the old order.
+    const char* ew_env = getenv("WUN_EARLY_WINDOW");
+    const bool early_win = !same && !p->bf16 && !(ew_env != nullptr && ew_env[0] == '0');
+    const bool early_all = early_win && ew_env != nullptr && ew_env[0] == 'a';
+    auto level_fused = [&](int i) {                                  // (the rule of the down-path loop below)
+        const DownShape& d = p->dsh[i];
+        ConvArgs f = conv_base(p);
+        f.Tin = d.t_dec; f.KW = p->down[i].J0; f.kw_full = Kd; f.N = f.N0 = d.cin; f.Tout = (d.t_in + 1) / 2; f.Tlim = d.t_in;
+        f.flags = F_PHASE2; f.C0 = d.cout; f.B = p->B;
+        return (d.cin & 3) == 0 && f.Tout >= 256 && conv_natural_wgs_phase2(f) >= 256;
+    };
+    auto level_early = [&](int i) { return early_win && i > 0 && (early_all || !level_fused(i)); };
     if (early_win && p->win_ev.size() < (size_t)L) {
         p->win_ev.resize(L, nullptr);
         for (auto& e : p->win_ev)
@@ -1225,7 +1235,7 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
             set_dst0(a, ws, p->dz_skip[i], 0, &p->skip[i]);
             set_dst1(a, ws, p->d_ups[j], 0, nullptr);
             HIP_TRY(conv_dispatch(p, a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
-            if (early_win && i > 0) pend_win.push_back(i);     // dz_skip[i] is final: its window input gradient can start
+            if (level_early(i)) pend_win.push_back(i);         // dz_skip[i] is final: its window input gradient can start
         }
         {
             const Buf& prev = (j == 0) ? p->bott_out : p->upo[j - 1];
@@ -1328,7 +1338,7 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
                 f.Tin = d.t_dec; f.KW = cl.J0; f.kw_full = Kd; f.shift = cl.J0 - 1; f.W = ws + cl.wt_ph2;
                 f.N = f.N0 = d.cin; f.Tout = (d.t_in + 1) / 2; f.Tlim = d.t_in; f.flags = F_PHASE2;
                 set_dst0(f, ws, p->dz_dec[i - 1], 0, &p->dec[i - 1]);
-                const bool win_early = early_win && !p->win_ev.empty();
+                const bool win_early = level_early(i) && !p->win_ev.empty();
                 if (win_early) {
                     // the window part is already in dz_dec[i-1] (side stream): wait for it, add inside the window
                     if (s2 != s) HIP_TRY(hipStreamWaitEvent(s, p->win_ev[(size_t)i], 0));
@@ -1387,7 +1397,7 @@ extern "C" int wun_plan_tune(const wun_plan* p, const float* params, const float
 // Tuning-table header: identifies the plan (every config key that changes a launch), the launch
 // order of this library build and the number of entries per section, so a table written for
 // another plan, another library build or truncated on disk is rejected at import.
-#define WUN_TUNE_ORDER "r3b"      /* bump whenever the order / number of conv or wgrad launches changes */
+#define WUN_TUNE_ORDER "r3c"      /* bump whenever the order / number of conv or wgrad launches changes */
 static std::string tune_header(const wun_plan* p, size_t ncf, size_t ncb, size_t nwg) {
     char line[320];
     const wun_config& c = p->cfg;
