@@ -21,7 +21,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${tag} -o ks -
     > $R/gpurun_out/${tag}_prof_bench.json 2> $R/gpurun_out/${tag}_prof_bench.err
 cp $(find /tmp/prof_${tag} -name "*kernel_stats.csv" | head -1) $R/gpurun_out/${tag}_kernel_stats.csv
 cp $(find /tmp/prof_${tag} -name "*kernel_trace.csv" | head -1) $R/gpurun_out/${tag}_kernel_trace.csv
-python $R/tools/timeline.py $R/gpurun_out/${tag}_kernel_trace.csv 2 $R/gpurun_out/${tag}_timeline.txt
+python $R/tools/timeline.py $R/gpurun_out/${tag}_kernel_trace.csv 6 $R/gpurun_out/${tag}_timeline.txt
 # same command with every launch on one stream: per-kernel durations free of overlap with the other
 # streams' kernels -- the figure bench.py's roofline (HIP events, single-stream profiled steps) must agree with
 rm -rf /tmp/prof1_${tag}
