@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Regenerate the per-config result tables of DESIGN.md (section 6) and BASELINE.md (section 4) from
-profiles/round2_bench.json and profiles/round2_cfg_*.json."""
+profiles/round3_bench.json and profiles/round3_cfg_*.json (the latest round's files)."""
 import glob
 import json
 import os
@@ -13,8 +13,8 @@ def last_json(path):
 
 
 def main():
-    b = last_json(os.path.join(ROOT, "profiles", "round2_bench.json"))
-    cfg = {f.split("round2_cfg_")[1][:-5]: last_json(f) for f in glob.glob(os.path.join(ROOT, "profiles", "round2_cfg_*.json"))}
+    b = last_json(os.path.join(ROOT, "profiles", "round3_bench.json"))
+    cfg = {f.split("round3_cfg_")[1][:-5]: last_json(f) for f in glob.glob(os.path.join(ROOT, "profiles", "round3_cfg_*.json"))}
     cb = b["cpu_baseline"]
     tf = lambda d: d["config"]["achieved_tflops_executed"]
 
@@ -41,8 +41,8 @@ def main():
     s = open(p).read()
     i = s.index("## 4. Results")
     r = []
-    r.append("| **M1 + context (configs[1], the bench line)**, 147 443 → 16 389 | 1 | fp32 | **%.3g** | **%.2f** | %.0f %% of the dense-graph compute roofline (3.79e7); on executed FLOPs (dead odd outputs skipped, SURVEY §8d) %.1f TFLOP/s = %.0f %% of 157.3; kernel family `conv_mfma_kernel` %.3f, `wgrad_mfma_kernel` %.3f | %.3g (%d cores, %s; whole batch) / %.3g (1 thread) | %.0f× |" % (
-        b["value"], b["ms_per_step"], 100 * b["value"] / 3.79e7, tf(b), 100 * tf(b) / 157.3, b["roofline"]["family_frac"]["conv_mfma_kernel"],
+    r.append("| **M1 + context (configs[1], the bench line)**, 147 443 → 16 389 | 1 | fp32 | **%.3g** | **%.2f** | executed FLOPs (dead odd outputs skipped, SURVEY §8d) %.1f TFLOP/s = %.0f %% of 157.3 (the reference graph's skipped FLOPs are NOT counted as achieved); kernel family `conv_mfma_kernel` %.3f, `wgrad_mfma_kernel` %.3f | %.3g (%d cores, %s; whole batch) / %.3g (1 thread) | %.0f× |" % (
+        b["value"], b["ms_per_step"], tf(b), 100 * tf(b) / 157.3, b["roofline"]["family_frac"]["conv_mfma_kernel"],
         b["roofline"]["family_frac"]["wgrad_mfma_kernel"], cb["value"], cb["cores"], cb["cpu_model"], cb["value_1_thread"], b["value"] / cb["value"]))
     r.append("| same | 1 | bf16 mode | %.3g | %.2f | — | — | — |" % (cfg["m1_context_bf16"]["value"], cfg["m1_context_bf16"]["ms_per_step"]))
     r.append("| M1 as shipped (same padding, configs[0]), T=16 384 | 1 | fp32 | %.3g | %.2f | %.0f %% of 1.76e8 (%.1f TFLOP/s) | — | — |" % (
@@ -61,13 +61,14 @@ def main():
         cfg["deep_f32"]["value"], cfg["deep_f32"]["ms_per_step"], 100 * tf(cfg["deep_f32"]) / 157.3, tf(cfg["deep_f32"])))
     r.append("| same | 1 | bf16 mode | %.3g | %.1f | %.1f %% of 6.9e8 | — | — |" % (cfg["deep_bf16"]["value"], cfg["deep_bf16"]["ms_per_step"],
                                                                              100 * cfg["deep_bf16"]["value"] / 6.9e8))
-    new = ("## 4. Results (round 2; 1×MI355X, B=16; `profiles/round2_bench.json`, `profiles/round2_cfg_*.json`)\n\n"
+    new = ("## 4. Results (round 3; 1×MI355X, B=16; `profiles/round3_bench.json`, `profiles/round3_cfg_*.json`)\n\n"
            "fp32 = the reference's arithmetic (exact-fp32 MFMA) — the only numbers comparable with the metric; bf16 mode = the speed mode of\n"
            "BASELINE.json configs[2], [4] (bf16 MFMA multiplicands, fp32 accumulate / storage / optimizer; DESIGN.md §5b), reported beside.\n\n"
            "| Config | GPUs | dtype | samples/s (out) | ms/step | fraction of the binding roofline | CPU baseline samples/s | speed-up |\n"
            "|---|---|---|---|---|---|---|---|\n" + "\n".join(r) + "\n\n"
            "Multi-GPU rows are measured by the driver (`SCALE_rNN.json`); none was measured so far (no multi-GPU node was available in\n"
-           "rounds 1-2).  Round-1 numbers of the same rows: 2.77e7 / 9.47 ms (M1 + context), 6.82e7 / 3.85 ms (M1), 327 ms (deep).\n"
+           "rounds 1-3; `python bench.py --gpus N` now launches itself).  Earlier rounds, same rows: round 1 2.77e7 / 9.47 ms (M1 + context),\n"
+           "6.82e7 / 3.85 ms (M1), 327 ms (deep); round 2 2.91e7 / 9.00 ms, 7.14e7 / 3.67 ms, 318 ms.\n"
            "(`tools/update_result_tables.py` regenerates this section and DESIGN.md's table from `profiles/`.)\n")
     open(p, "w").write(s[:i] + new)
     print("\n".join(rows))
