@@ -138,3 +138,34 @@ def test_validation_loss_is_rank0s_on_every_rank(tmp_path):
     r0 = open(os.path.join(str(tmp_path), "r0.txt")).read().split()
     r1 = open(os.path.join(str(tmp_path), "r1.txt")).read().split()
     assert r0 == ["0.25", "1"] and r1 == ["0.25", "0"]
+
+
+def _failing_validation_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    init_distributed(backend="gloo")
+    from wave_u_net_amd import validation
+
+    def fake_test(model_config, partition, model_folder, load_model, tracks=None, **kw):
+        raise ValueError("checkpoint is corrupt")          # only rank 0 ever calls it
+
+    validation.test = fake_test
+    try:
+        validation._rank0_test({}, "valid", "x", None, [])
+        got = "no exception"
+    except RuntimeError as e:
+        got = str(e)
+    with open(os.path.join(out_dir, "r%d.txt" % rank), "w") as f:
+        f.write(got)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_validation_failure_on_rank0_raises_on_every_rank(tmp_path):
+    """A failure of rank 0's validation must not leave the other ranks parked in the broadcast:
+    the error text is broadcast and every rank raises."""
+    port = _free_port()
+    mp.spawn(_failing_validation_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in (0, 1):
+        got = open(os.path.join(str(tmp_path), "r%d.txt" % r)).read()
+        assert "validation on rank 0 failed" in got and "checkpoint is corrupt" in got, (r, got)

@@ -99,13 +99,22 @@ def _rank0_test(model_config, partition, model_folder, load_model, tracks):
     that disagreed would leave the next epoch's gradient all-reduce waiting forever."""
     import torch.distributed as dist
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-    loss = None
+    loss, err = None, None
     if not multi or dist.get_rank() == 0:
-        loss = test(model_config, partition, model_folder, load_model, tracks=tracks)
+        try:
+            loss = test(model_config, partition, model_folder, load_model, tracks=tracks)
+        except Exception as e:                       # noqa: BLE001 -- re-raised below, on EVERY rank
+            if not multi:
+                raise
+            err = "%s: %s" % (type(e).__name__, e)
     if multi:
-        box = [loss]
+        # rank 0's failure (bad checkpoint, ValueError from test()) reaches the waiting ranks instead of leaving them
+        # parked in the collective until the watchdog fires (ADVICE round 2)
+        box = [loss, err]
         dist.broadcast_object_list(box, src=0)
-        loss = box[0]
+        loss, err = box
+        if err is not None:
+            raise RuntimeError("validation on rank 0 failed: " + err)
     return loss
 
 
