@@ -210,10 +210,15 @@ def test_conv_every_variant_strided_output(lib, case):
 PHASE2_CASES = [
     # (B, Cin, Cout, K, T_in): input gradient of a stride-2 valid conv; Cin (the GEMM N) decides which
     # fused two-phase tiles (32/64/96 columns = 16/32/48 channels x 2 phases) are legal
-    (2, 48, 72, 15, 1201),
+    # rows long enough that the op entry takes the FUSED launch (>= 64 natural workgroups; shorter rows fall back to
+    # two strided single-phase launches, which the last case keeps covered): 24 / 72 exercise the packed 24-channel
+    # tiles (NW == 3, lane exchange in the epilogue), odd and even T the scalar / vector store paths
+    (2, 24, 48, 15, 73715),
+    (2, 72, 96, 15, 20004),
+    (2, 48, 72, 15, 24001),
+    (3, 32, 40, 15, 16100),
+    (2, 96, 24, 7, 12000),
     (2, 24, 48, 15, 1400),
-    (2, 32, 40, 15, 1100),
-    (2, 96, 24, 7, 1000),
 ]
 
 

@@ -735,55 +735,93 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
     // phase 0 (t = 2q), tiles [NW/2, NW) phase 1 (t = 2q+1) of the same channels, so a lane
     // owns 8 consecutive output samples ----
     if (phase2) {
-        if constexpr (WN == 1 && (NW % 2) == 0) {
+        if constexpr (WN == 1 && ((NW % 2) == 0 || NW == 3)) {
             const bool vec2 = (a.flags & F_VEC4) != 0;
             const bool accum2 = (a.flags & F_ACCUM) != 0;
-#pragma unroll
-            for (int n = 0; n < NW / 2; ++n) {
-                const int ncol = n0h + n * 16 + li;
-                if (ncol >= a.N) continue;
+            // 8 consecutive outputs t = 2q .. 2q+7 of channel `ncol` (v[2r] = phase 0, v[2r+1] = phase 1 of position q + r)
+            auto store8 = [&](int ncol, int m, float (&v)[8]) {
                 const long long rowbase = (long long)b_st * a.obs0 + (long long)ncol * a.opitch0 + a.ooff0;
+                const int q = q0_st + wt0 + m * 16 + lg * 4;
+                const int t0 = 2 * q;
+                if (vec2 && t0 + 7 < a.Tlim) {
+                    const long long idx = rowbase + t0;
+                    if (a.msk0 != nullptr) {
+                        const f32x4 m0 = *reinterpret_cast<const f32x4*>(&a.msk0[idx]);
+                        const f32x4 m1 = *reinterpret_cast<const f32x4*>(&a.msk0[idx + 4]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            v[r] *= (m0[r] > 0.f) ? 1.f : 0.2f;
+                            v[4 + r] *= (m1[r] > 0.f) ? 1.f : 0.2f;
+                        }
+                    }
+                    const int pos0 = a.ooff0 + t0;
+                    if (accum2 && (conv_acc_at(a, pos0) || conv_acc_at(a, pos0 + 7))) {      // (the window is wider than 8)
+                        const f32x4 o0 = *reinterpret_cast<const f32x4*>(&a.dst0[idx]);
+                        const f32x4 o1 = *reinterpret_cast<const f32x4*>(&a.dst0[idx + 4]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (conv_acc_at(a, pos0 + r)) v[r] += o0[r];
+                            if (conv_acc_at(a, pos0 + 4 + r)) v[4 + r] += o1[r];
+                        }
+                    }
+                    *reinterpret_cast<f32x4*>(&a.dst0[idx]) = (f32x4){v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(&a.dst0[idx + 4]) = (f32x4){v[4], v[5], v[6], v[7]};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        if (t0 + r < a.Tlim) {
+                            const long long idx = rowbase + t0 + r;
+                            float x = v[r];
+                            if (a.msk0 != nullptr) x *= (a.msk0[idx] > 0.f) ? 1.f : 0.2f;
+                            if (accum2 && conv_acc_at(a, a.ooff0 + t0 + r)) x += a.dst0[idx];
+                            a.dst0[idx] = x;
+                        }
+                    }
+                }
+            };
+            if constexpr ((NW % 2) == 0) {
+#pragma unroll
+                for (int n = 0; n < NW / 2; ++n) {
+                    const int ncol = n0h + n * 16 + li;
+                    if (ncol >= a.N) continue;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        float v[8];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { v[2 * r] = acc[m][n][r]; v[2 * r + 1] = acc[m][NW / 2 + n][r]; }
+                        store8(ncol, m, v);
+                    }
+                }
+            } else {
+                // 24 channels per workgroup (the channel counts of this network are multiples of 24: no padded columns,
+                // where 16-channel tiles pad 24 -> 32, 72 -> 80, 120 -> 128, 168 -> 176): columns [0, 24) = phase 0,
+                // [24, 48) = phase 1 of the same channels, i.e. MFMA column blocks {ph0 ch 0-15}, {ph0 ch 16-23 | ph1 ch 0-7},
+                // {ph1 ch 8-23}.  The phase-1 partner of a lane's phase-0 value sits 8 lanes away in the same 16-lane row
+                // (DPP row rotate by 8): lanes 0-7 own channels li and 16 + li, lanes 8-15 channel li.
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    const int q = q0_st + wt0 + m * 16 + lg * 4;
-                    const int t0 = 2 * q;
-                    float v[8];
+                    float p1[4], p2[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { v[2 * r] = acc[m][n][r]; v[2 * r + 1] = acc[m][NW / 2 + n][r]; }
-                    if (vec2 && t0 + 7 < a.Tlim) {
-                        const long long idx = rowbase + t0;
-                        if (a.msk0 != nullptr) {
-                            const f32x4 m0 = *reinterpret_cast<const f32x4*>(&a.msk0[idx]);
-                            const f32x4 m1 = *reinterpret_cast<const f32x4*>(&a.msk0[idx + 4]);
+                    for (int r = 0; r < 4; ++r) {
+                        // (copy the vector element to a scalar first: __builtin_bit_cast applied to an ext-vector element
+                        // lvalue reads element 0 with this compiler)
+                        const float s1 = acc[m][1][r], s2 = acc[m][2][r];
+                        p1[r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0x128, 0xF, 0xF, false));
+                        p2[r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2), 0x128, 0xF, 0xF, false));
+                    }
+                    const int cA = n0h + li;
+                    if (cA < a.N) {
+                        float v[8];
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                v[r] *= (m0[r] > 0.f) ? 1.f : 0.2f;
-                                v[4 + r] *= (m1[r] > 0.f) ? 1.f : 0.2f;
-                            }
-                        }
-                        const int pos0 = a.ooff0 + t0;
-                        if (accum2 && (conv_acc_at(a, pos0) || conv_acc_at(a, pos0 + 7))) {      // (the window is wider than 8)
-                            const f32x4 o0 = *reinterpret_cast<const f32x4*>(&a.dst0[idx]);
-                            const f32x4 o1 = *reinterpret_cast<const f32x4*>(&a.dst0[idx + 4]);
+                        for (int r = 0; r < 4; ++r) { v[2 * r] = acc[m][0][r]; v[2 * r + 1] = li < 8 ? p1[r] : p2[r]; }
+                        store8(cA, m, v);
+                    }
+                    const int cB = n0h + 16 + li;
+                    if (li < 8 && cB < a.N) {
+                        float v[8];
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                if (conv_acc_at(a, pos0 + r)) v[r] += o0[r];
-                                if (conv_acc_at(a, pos0 + 4 + r)) v[4 + r] += o1[r];
-                            }
-                        }
-                        *reinterpret_cast<f32x4*>(&a.dst0[idx]) = (f32x4){v[0], v[1], v[2], v[3]};
-                        *reinterpret_cast<f32x4*>(&a.dst0[idx + 4]) = (f32x4){v[4], v[5], v[6], v[7]};
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) {
-                            if (t0 + r < a.Tlim) {
-                                const long long idx = rowbase + t0 + r;
-                                float x = v[r];
-                                if (a.msk0 != nullptr) x *= (a.msk0[idx] > 0.f) ? 1.f : 0.2f;
-                                if (accum2 && conv_acc_at(a, a.ooff0 + t0 + r)) x += a.dst0[idx];
-                                a.dst0[idx] = x;
-                            }
-                        }
+                        for (int r = 0; r < 4; ++r) { v[2 * r] = acc[m][1][r]; v[2 * r + 1] = p2[r]; }
+                        store8(cB, m, v);
                     }
                 }
             }
@@ -1058,12 +1096,13 @@ int conv_pick_variant_phase2(const ConvArgs& a) {
     const int pad256 = ((a.Tout + 255) / 256) * 256, pad128 = ((a.Tout + 127) / 128) * 128;
     const bool t128 = pad128 < pad256;
     int best = 2, bestpad = 1 << 30;                 // channels per workgroup = NW*8
-    const int cands[3] = {6, 4, 2};
-    for (int i = 0; i < 3; ++i) {
+    const int cands[4] = {6, 4, 3, 2};               // (3: the packed 24-channel tile -- exact for this network's widths)
+    for (int i = 0; i < 4; ++i) {
         const int half = cands[i] * 8;
         const int padded = ((a.N + half - 1) / half) * half;
         if (padded < bestpad) { bestpad = padded; best = cands[i]; }
     }
+    if (best == 3) return t128 ? 5 : 1;              // 128 / 256 x 48
     if (best == 6) return 15;                        // 128 x 96 keeps 3 waves/SIMD
     if (best == 4) return t128 ? 6 : 2;
     return t128 ? 4 : 0;
@@ -1227,7 +1266,7 @@ bool conv_choice_ok(const ConvArgs& a, long long part_cap, int v, int ks) {
     const ConvVariant& cv = kConvVariants[v];
     if (Ctot <= 4 && cv.CK != 4) return false;
     if (Ctot > 4 && cv.CK == 4 && (a.loader == LOADER_DEINT || phase2 || v < 26)) return false;
-    if (phase2 && !(cv.WN == 1 && (cv.NW % 2) == 0)) return false;
+    if (phase2 && !(cv.WN == 1 && ((cv.NW % 2) == 0 || cv.NW == 3))) return false;
     if (cv.fold && !conv_fold_ok(a, v)) return false;
     const int TT = cv.WT * cv.MT * 16;
     const int NT = phase2 ? cv.WN * cv.NW * 8 : cv.WN * cv.NW * 16;   // channels per workgroup
