@@ -6,6 +6,7 @@
   python -m wave_u_net_amd train   with cfg.m1_context synthetic=1 experiment_id=7
   python -m wave_u_net_amd predict with cfg.full model_path=ckpt.npz input_path=mix.wav output_path=out
   python -m wave_u_net_amd test    with cfg.baseline model_path=ckpt.npz data_root=DATA partition=valid
+(model_path / load_model: a .npz of this package or a TensorFlow V2 checkpoint prefix such as checkpoints/full_44KHz/full_44KHz-236118)
 
 `with` arguments: `cfg.<named config>` (any of wave_u_net_amd.NAMED_CONFIGS), `model_config.<key>=<value>`
 overrides, and the command's own options as `<name>=<value>`.  data_root holds

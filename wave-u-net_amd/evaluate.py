@@ -70,8 +70,8 @@ def produce_source_estimates(model_config, load_model, input_path, output_path=N
     audio = datasets.load_audio(input_path, mono=False, expected_sr=model_config["expected_sr"])
     sep = separator if separator is not None else UnetAudioSeparator(model_config)
     if load_model is not None:
-        state = np.load(load_model)
-        sep.load_variables({k: state[k] for k in state.files if k.startswith("separator/")})
+        from .checkpoint import load_checkpoint
+        load_checkpoint(sep, load_model, with_optimizer=False)     # .npz or a TensorFlow V2 checkpoint prefix
     preds = predict_track(model_config, sep, audio, model_config["expected_sr"])
     # Evaluate.predict (:59-80): mono models are evaluated on the downmix; estimates are tiled back to
     # the input's channel count

@@ -17,6 +17,7 @@ import torch
 import torch.distributed as dist
 
 from .parallel import GradAllReducer, OverlappedGradAllReducer, broadcast_parameters, init_distributed
+from .checkpoint import load_checkpoint, save_checkpoint
 from .separator import UnetAudioSeparator
 
 
@@ -144,13 +145,9 @@ def train(model_config, experiment_id, load_model=None, batch_source=None, log_e
         # rank 0 reads the checkpoint (the only rank that is guaranteed to have the path: train()
         # hands save_path to every rank, but the file system need not be shared); parameters, both
         # Adam slots and global_step are then broadcast so every replica resumes the SAME state
+        # (`.npz` of this package, or a TensorFlow V2 checkpoint prefix as the reference's Saver writes: checkpoint.py)
         if tr.rank == 0:
-            state = np.load(load_model)
-            tr.sep.load_variables({k: state[k] for k in state.files if k.startswith("separator/")})
-            if "adam_m" in state.files:
-                tr.sep.adam_m.copy_(torch.from_numpy(state["adam_m"]))
-                tr.sep.adam_v.copy_(torch.from_numpy(state["adam_v"]))
-            tr.sep.global_step = int(state["global_step"])
+            load_checkpoint(tr.sep, load_model)
         if tr.world > 1:
             for t in (tr.sep.params, tr.sep.adam_m, tr.sep.adam_v):
                 broadcast_parameters(t)
@@ -180,12 +177,12 @@ def train(model_config, experiment_id, load_model=None, batch_source=None, log_e
     if tr.rank == 0:                                                # Training.py:113
         ckpt_dir = os.path.join(model_config["model_base_dir"], str(experiment_id))
         os.makedirs(ckpt_dir, exist_ok=True)
-        save_path = os.path.join(ckpt_dir, "%s-%d.npz" % (experiment_id, tr.sep.global_step))
-        arrays = {n: v.detach().cpu().numpy() for n, v in tr.sep.variables().items()}
-        arrays["adam_m"] = tr.sep.adam_m.cpu().numpy()
-        arrays["adam_v"] = tr.sep.adam_v.cpu().numpy()
-        arrays["global_step"] = np.int64(tr.sep.global_step)
-        np.savez(save_path, **arrays)
+        # Training.py:113 saves "<dir>/<id>-<step>" with the V2 Saver; model_config["checkpoint_format"] = "tf" writes
+        # exactly that (restorable by the reference), the default is this package's .npz
+        if model_config.get("checkpoint_format", "npz") == "tf":
+            save_path = save_checkpoint(tr.sep, os.path.join(ckpt_dir, "%s-%d" % (experiment_id, tr.sep.global_step)), "tf")
+        else:
+            save_path = save_checkpoint(tr.sep, os.path.join(ckpt_dir, "%s-%d.npz" % (experiment_id, tr.sep.global_step)))
         log.close()
     if tr.world > 1:
         # every rank returns the checkpoint path (Training.py:121 has one process; here the callers --

@@ -16,12 +16,11 @@ import torch
 from . import datasets
 from .separator import UnetAudioSeparator
 from .training import train
+from .checkpoint import load_checkpoint
 
 
 def _load_checkpoint(separator, load_model):
-    state = np.load(load_model)
-    separator.load_variables({k: state[k] for k in state.files if k.startswith("separator/")})
-    return int(state["global_step"]) if "global_step" in state.files else 0
+    return load_checkpoint(separator, load_model, with_optimizer=False)
 
 
 def test(model_config, partition, model_folder, load_model, tracks=None, data_root=None, separator=None):
