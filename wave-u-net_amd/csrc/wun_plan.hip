@@ -607,6 +607,10 @@ static float time_once(const wun_plan* p, hipStream_t s, const std::function<hip
     return ms;
 }
 
+// WUN_TUNE_ALTS log: how many near-best candidates per launch position, and how near (tools/step_tune.py)
+static size_t alts_max() { const char* e = getenv("WUN_TUNE_ALTS_MAX"); const int v = e ? atoi(e) : 6; return (size_t)(v > 0 ? v : 6); }
+static float alts_tol() { const char* e = getenv("WUN_TUNE_ALTS_TOL"); const float v = e ? (float)atof(e) : 1.15f; return v > 1.f ? v : 1.15f; }
+
 // Times `n` candidate launches of ONE launch position against each other: every candidate is warmed up once, then
 // the candidates are run round-robin for WUN_TUNE_ROUNDS rounds (default 4) and each keeps its fastest run.  The shader
 // clock of a busy MI355X drifts by ~10 % over milliseconds (DVFS); timing candidates one after the other in a single
@@ -687,12 +691,12 @@ static hipError_t conv_dispatch(const wun_plan* p, ConvArgs a, float* part, long
         if (const char* af = getenv("WUN_TUNE_ALTS")) {
             // near-best candidates of this position (isolated timing) for the whole-step tuner, tools/step_tune.py
             if (FILE* f = fopen(af, "a")) {
-                const float lim = std::min(best, base) * 1.15f;
+                const float lim = std::min(best, base) * alts_tol();
                 fprintf(f, "%s %zu %d %d %.4f\n", p->in_bwd ? "cb" : "cf", idx, -1, 0, base);
                 std::vector<int> order;
                 for (int i = 0; i < n; ++i) if (tms[i] <= lim) order.push_back(i);
                 std::sort(order.begin(), order.end(), [&](int x, int y) { return tms[x] < tms[y]; });
-                for (size_t k = 0; k < order.size() && k < 6; ++k)
+                for (size_t k = 0; k < order.size() && k < alts_max(); ++k)
                     fprintf(f, "%s %zu %d %d %.4f\n", p->in_bwd ? "cb" : "cf", idx, cands[order[k]].variant, cands[order[k]].ksplit, tms[order[k]]);
                 fclose(f);
             }
@@ -971,11 +975,11 @@ static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const Conv
         if (bi > 0 && tms[bi] < base * 0.98f) { best = tms[bi]; bc = cv[bi].c; }
         if (const char* af = getenv("WUN_TUNE_ALTS")) {
             if (FILE* f = fopen(af, "a")) {
-                const float lim = std::min(best, base) * 1.15f;
+                const float lim = std::min(best, base) * alts_tol();
                 std::vector<size_t> order;
                 for (size_t i = 0; i < cv.size(); ++i) if (tms[i] <= lim) order.push_back(i);
                 std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return tms[x] < tms[y]; });
-                for (size_t k = 0; k < order.size() && k < 6; ++k) {
+                for (size_t k = 0; k < order.size() && k < alts_max(); ++k) {
                     const WgradChoice& c = cv[order[k]].c;
                     fprintf(f, "wg %zu %d %d %d %d %.4f\n", idx, c.mtw, c.nw, c.nsplit[0], c.nsplit[1], tms[order[k]]);
                 }
