@@ -57,7 +57,14 @@ struct ConvArgs {
     // skip-window conv over the crop window: the window part is computed EARLY on a side stream, the row-wide part
     // adds it inside the window.)  acc_len == 0 is normalised by launch_conv to "the whole row".
     int acc_lo; unsigned acc_len;
+    // Fused 2x upsampling of the dst0 output (UnetAudioSeparator.py:109-118, InterpolationLayer.py:19-39): when the launch
+    // ends in the split-K epilogue kernel, that kernel also writes ups_y[b][c][0 .. ups_tup) = {y[i], interp(y[i], y[i+1])}
+    // (ups_w: learned per-channel weights before the sigmoid, or null = linear; ups_tup = 2n - 1 with context, 2n without)
+    // -- the same arithmetic as upsample_vec_kernel, which the caller then does not launch (conv_last_fused_ups()).
+    float* ups_y; long long ups_bs; int ups_pitch; int ups_tup; const float* ups_w;
 };
+// did the last launch_conv() on this thread write the fused upsampled copy?  (only split-K launches do)
+int conv_last_fused_ups();
 __host__ __device__ static inline bool conv_acc_at(const ConvArgs& a, int pos) { return (unsigned)(pos - a.acc_lo) < a.acc_len; }
 
 // Weight/bias gradient launch:  P[split][ (k*C + c)*N + n ] and bias row P[split][KW*C*N + n]

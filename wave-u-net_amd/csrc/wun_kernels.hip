@@ -1014,8 +1014,49 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvArgs a, i
                 }
             }
         }
+        if (a.ups_y != nullptr && ncol < a.N0 && q < a.Tout) {
+            // fused 2x upsampling of this row segment (forward launches: no mask, no accumulate, so v is the stored
+            // activation): out[2i] = y[i], out[2i+1] = interp(y[i], y[i+1]).  y[q+4] belongs to the next thread: its
+            // partials are summed again here in the same order (bit-identical to what that thread stores).
+            const int n = a.Tout;
+            float y[5];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = v[r];
+            y[4] = 0.f;
+            if (q + 4 < n) {
+                float t = 0.f;
+                for (int k2 = 0; k2 < ksplit; ++k2) t += pp[(long long)k2 * sstride + 4];
+                t += bvv;
+                if (lrelu) t = fmaxf(0.2f * t, t);
+                y[4] = t;
+            }
+            float* up = a.ups_y + (long long)b * a.ups_bs + (long long)ncol * a.ups_pitch;
+            float sg = 0.f;
+            if (a.ups_w != nullptr) sg = 1.f / (1.f + __expf(-a.ups_w[ncol]));
+            float o[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = q + r;
+                const bool has_next = i + 1 < n;
+                const float x0 = y[r], x1 = has_next ? y[r + 1] : 0.f;
+                o[2 * r] = x0;
+                o[2 * r + 1] = (a.ups_w != nullptr) ? sg * x0 + (1.f - sg) * x1            // SAME: one zero on the right
+                                                    : 0.5f * (x0 + (has_next ? x1 : x0)); // legacy bilinear clamps
+            }
+            const int t0 = 2 * q;
+            if (t0 + 7 < a.ups_tup && q + 3 < n && (a.ups_pitch & 3) == 0 && (a.ups_bs & 3) == 0) {
+                *reinterpret_cast<f32x4*>(up + t0) = (f32x4){o[0], o[1], o[2], o[3]};
+                *reinterpret_cast<f32x4*>(up + t0 + 4) = (f32x4){o[4], o[5], o[6], o[7]};
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    if (q + (r >> 1) < n && t0 + r < a.ups_tup) up[t0 + r] = o[r];
+            }
+        }
     }
 }
+
+static thread_local int t_last_fused_ups = 0;       // conv_last_fused_ups()
 
 // variant table -------------------------------------------------------------------------
 struct ConvVariant { int MT, NW, WT, WN, CK, fold; };
@@ -1250,6 +1291,7 @@ static hipError_t conv_launch_t(ConvArgs a, int variant, float* part, long long 
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, ksplit);
+    t_last_fused_ups = a.ups_y != nullptr ? 1 : 0;
     return hipGetLastError();
 }
 
@@ -1300,8 +1342,15 @@ int conv_list_candidates(const ConvArgs& a, long long part_cap, ConvChoice* out,
 int conv_num_variants() { return (int)(sizeof(kConvVariants) / sizeof(kConvVariants[0])); }
 
 
+int conv_last_fused_ups() { return t_last_fused_ups; }
+
 hipError_t launch_conv(const ConvArgs& a_in, float* part, long long part_cap, hipStream_t s) {
     ConvArgs a = a_in;
+    t_last_fused_ups = 0;
+    // the fused upsampled copy is written by the split-K epilogue of plain forward launches only
+    if (a.ups_y != nullptr && (a.dst1 != nullptr || a.msk0 != nullptr || a.ostride != 1 || a.ooff0 != 0 ||
+                               (a.flags & (F_ACCUM | F_PHASE2)) != 0 || a.N0 != a.N || !aligned16(a.ups_y)))
+        return hipErrorInvalidValue;
     if (a.acc_len == 0) { a.acc_lo = 0; a.acc_len = 0x7FFFFFFFu; }          // F_ACCUM over the whole row (default)
     if (conv_J(a) > WUN_JMAX) return hipErrorInvalidValue;       // rejected at plan creation
     if (a.KW <= 0) {

@@ -677,6 +677,7 @@ static hipError_t conv_dispatch(const wun_plan* p, ConvArgs a, float* part, long
         // candidate n = the heuristic choice (the baseline); a candidate has to beat it by > 2 %
         time_candidates(p, s, n + 1, [&](int i) {
             ConvArgs b = a;
+            b.ups_y = nullptr;                  // (candidates are compared without the fused upsampled copy only split-K ones write)
             if (i < n) { b.force_variant = cands[i].variant + 1; b.force_ksplit = cands[i].ksplit; }
             return launch_conv(b, part, cap, s);
         }, tms);
@@ -774,6 +775,17 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
     std::vector<long long> deferred_pos((size_t)defer_below, -1);
     const long long part_half = p->conv_part_floats / 2, part_q = p->conv_part_floats / 4;
 
+    // The 2x upsampling that opens up level j reads only the producer's output (bottleneck conv for j = 0, up conv
+    // j - 1 otherwise).  A producer launch that ends in the split-K epilogue kernel -- 10 of the 12 on the headline
+    // configuration -- writes the upsampled copy from there (ConvArgs.ups_*): one launch less on the dependent chain per
+    // level; the others still launch upsample_vec_kernel.  WUN_NO_FUSE_UPS=1: always the separate kernel.
+    const bool fuse_ups = !p->bf16 && getenv("WUN_NO_FUSE_UPS") == nullptr;
+    bool ups_done = false;
+    auto want_ups = [&](ConvArgs& a, int j) {
+        a.ups_y = ws + p->ups[j].off; a.ups_bs = p->ups[j].bs; a.ups_pitch = p->ups[j].pitch; a.ups_tup = p->ush[j].t_up;
+        a.ups_w = p->interp[j] >= 0 ? params + p->interp[j] : nullptr;
+    };
+
     const Buf* x = &p->mix_ncw;
     for (int i = 0; i < L; ++i) {                                   // :97-100
         const DownShape& d = p->dsh[i];
@@ -831,19 +843,24 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
         a.Tin = p->t_b_in; a.shift = padD; a.W = params + p->bott.woff; a.bias = params + p->bott.boff;
         a.KW = Kd; a.N = a.N0 = p->c_b; a.Tout = p->t_b; a.flags = F_LRELU;
         set_dst0(a, ws, p->bott_out, 0, nullptr);
+        if (fuse_ups) want_ups(a, 0);
         HIP_TRY(conv_dispatch(p, a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
+        ups_done = fuse_ups && conv_last_fused_ups() != 0;
     }
     if (side_used && (rc0 = stream_dep(p, s2, s))) return rc0;     // the up path reads the skip windows
     const Buf* cur = &p->bott_out;
     for (int j = 0; j < L; ++j) {                                   // :107-125
         const UpShape& u = p->ush[j];
-        UpsampleArgs ua;
-        memset(&ua, 0, sizeof(ua));
-        ua.x = ws + cur->off; ua.xbs = cur->bs; ua.xpitch = cur->pitch; ua.n = u.t_cur;
-        ua.y = ws + p->ups[j].off; ua.ybs = p->ups[j].bs; ua.ypitch = p->ups[j].pitch; ua.tup = u.t_up;
-        ua.w = p->interp[j] >= 0 ? params + p->interp[j] : nullptr;
-        ua.C = u.c_cur; ua.B = p->B; ua.context = p->cfg.context;
-        HIP_TRY(launch_upsample(ua, s));
+        if (!ups_done) {
+            // (the producer's launch did not end in the split-K epilogue kernel, which writes this copy itself)
+            UpsampleArgs ua;
+            memset(&ua, 0, sizeof(ua));
+            ua.x = ws + cur->off; ua.xbs = cur->bs; ua.xpitch = cur->pitch; ua.n = u.t_cur;
+            ua.y = ws + p->ups[j].off; ua.ybs = p->ups[j].bs; ua.ypitch = p->ups[j].pitch; ua.tup = u.t_up;
+            ua.w = p->interp[j] >= 0 ? params + p->interp[j] : nullptr;
+            ua.C = u.c_cur; ua.B = p->B; ua.context = p->cfg.context;
+            HIP_TRY(launch_upsample(ua, s));
+        }
         if (L - 1 - j < defer_below) HIP_TRY(hipStreamWaitEvent(s, p->skip_ev[(size_t)(L - 1 - j)], 0));
         ConvArgs a = conv_base(p);
         set_src0(a, ws, p->skip[L - 1 - j], 0, u.c_skip);          // crop already applied when it was written
@@ -851,7 +868,9 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
         a.Tin = u.t_up; a.shift = padU; a.W = params + p->up[j].woff; a.bias = params + p->up[j].boff;
         a.KW = Ku; a.N = a.N0 = u.cout; a.Tout = u.t_conv; a.flags = F_LRELU;
         set_dst0(a, ws, p->upo[j], 0, nullptr);
+        if (fuse_ups && j + 1 < L) want_ups(a, j + 1);
         HIP_TRY(conv_dispatch(p, a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
+        ups_done = fuse_ups && j + 1 < L && conv_last_fused_ups() != 0;
         cur = &p->upo[j];
     }
     HeadArgs h = head_args(p, params, ws, outputs, training);
