@@ -1,6 +1,7 @@
 """Fused 2x upsampling (UnetAudioSeparator.py:109-118, InterpolationLayer.py:19-39): a producer launch that ends in the
-split-K epilogue kernel writes the upsampled copy of its output from there; `WUN_NO_FUSE_UPS=1` launches
-`upsample_vec_kernel` for every level instead.  Both must give the same network: outputs, loss and every gradient
+split-K epilogue kernel writes the upsampled copy of its output from there, and (linear interpolation) the split-K
+epilogue of the up conv's input gradient applies the adjoint instead of storing d_up; `WUN_NO_FUSE_UPS=1` launches
+`upsample_vec_kernel` / `upsample_bwd_vec_kernel` for every level instead.  Both must give the same network: outputs, loss and every gradient
 (the backward pass reads the upsampled tensors), bit for bit with linear interpolation and to one rounding of the
 interpolation with learned weights (the two kernels may contract `s*a + (1-s)*b` differently)."""
 import os

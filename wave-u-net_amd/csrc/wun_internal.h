@@ -62,6 +62,10 @@ struct ConvArgs {
     // (ups_w: learned per-channel weights before the sigmoid, or null = linear; ups_tup = 2n - 1 with context, 2n without)
     // -- the same arithmetic as upsample_vec_kernel, which the caller then does not launch (conv_last_fused_ups()).
     float* ups_y; long long ups_bs; int ups_pitch; int ups_tup; const float* ups_w;
+    // ... and its adjoint for the dst1 columns of an up conv's input gradient (linear interpolation only): instead of
+    // storing d_up, the split-K epilogue writes ubw_dz[b][c][i] = (d_up[2i] + wa d_up[2i+1] + 1/2 d_up[2i-1]) *
+    // LeakyReLU'(ubw_x[b][c][i]) -- the arithmetic of upsample_bwd_vec_kernel; rows of ubw_dz / ubw_x share one geometry.
+    float* ubw_dz; const float* ubw_x; long long ubw_bs; int ubw_pitch; int ubw_n;
 };
 // did the last launch_conv() on this thread write the fused upsampled copy?  (only split-K launches do)
 int conv_last_fused_ups();

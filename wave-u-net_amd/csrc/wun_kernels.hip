@@ -983,7 +983,29 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvArgs a, i
             v[r] += bvv;
             if (lrelu) v[r] = fmaxf(0.2f * v[r], v[r]);
         }
-        if (vpath) {
+        if (a.ubw_dz != nullptr && ncol >= a.N0) {
+            // fused adjoint of the 2x linear upsampling (no mask / accumulate on these columns: v = d_up[q .. q+3]).
+            // d_up[q-1] belongs to the previous thread: its partials are summed again here in the same order.
+            const int n = a.ubw_n, tup = a.Tout, c = ncol - a.N0;
+            float prev = 0.f;
+            if (q >= 1) {
+                float t = 0.f;
+                for (int k2 = 0; k2 < ksplit; ++k2) t += pp[(long long)k2 * sstride - 1];
+                prev = t + bvv;
+            }
+            const long long xr = (long long)b * a.ubw_bs + (long long)c * a.ubw_pitch;
+            const float d0 = v[0], d1 = q + 1 < tup ? v[1] : 0.f, d2 = q + 2 < tup ? v[2] : 0.f, d3 = q + 3 < tup ? v[3] : 0.f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = (q >> 1) + h;
+                if (i < n) {
+                    float g = h ? d2 : d0;                                           // d_up[2i]
+                    if (2 * i + 1 < tup) g += ((i == n - 1) ? 1.f : 0.5f) * (h ? d3 : d1);   // same-mode clamp: out[2n-1] = x[n-1]
+                    if (i >= 1) g += 0.5f * (h ? d1 : prev);
+                    a.ubw_dz[xr + i] = g * ((a.ubw_x[xr + i] > 0.f) ? 1.f : 0.2f);
+                }
+            }
+        } else if (vpath) {
             const long long idx = rowbase + q;
             if (msk != nullptr) {
 #pragma unroll
@@ -1291,7 +1313,7 @@ static hipError_t conv_launch_t(ConvArgs a, int variant, float* part, long long 
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, ksplit);
-    t_last_fused_ups = a.ups_y != nullptr ? 1 : 0;
+    t_last_fused_ups = (a.ups_y != nullptr || a.ubw_dz != nullptr) ? 1 : 0;
     return hipGetLastError();
 }
 
@@ -1350,6 +1372,10 @@ hipError_t launch_conv(const ConvArgs& a_in, float* part, long long part_cap, hi
     // the fused upsampled copy is written by the split-K epilogue of plain forward launches only
     if (a.ups_y != nullptr && (a.dst1 != nullptr || a.msk0 != nullptr || a.ostride != 1 || a.ooff0 != 0 ||
                                (a.flags & (F_ACCUM | F_PHASE2)) != 0 || a.N0 != a.N || !aligned16(a.ups_y)))
+        return hipErrorInvalidValue;
+    // ... the fused adjoint by the split-K epilogue of an input-gradient launch with two destinations, dst1 unmasked
+    if (a.ubw_dz != nullptr && (a.dst1 == nullptr || a.msk1 != nullptr || a.ostride != 1 || a.bias != nullptr ||
+                                (a.flags & (F_ACCUM | F_PHASE2 | F_LRELU)) != 0 || a.N0 >= a.N || a.ubw_x == nullptr))
         return hipErrorInvalidValue;
     if (a.acc_len == 0) { a.acc_lo = 0; a.acc_len = 0x7FFFFFFFu; }          // F_ACCUM over the whole row (default)
     if (conv_J(a) > WUN_JMAX) return hipErrorInvalidValue;       // rejected at plan creation

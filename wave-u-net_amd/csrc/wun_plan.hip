@@ -677,7 +677,7 @@ static hipError_t conv_dispatch(const wun_plan* p, ConvArgs a, float* part, long
         // candidate n = the heuristic choice (the baseline); a candidate has to beat it by > 2 %
         time_candidates(p, s, n + 1, [&](int i) {
             ConvArgs b = a;
-            b.ups_y = nullptr;                  // (candidates are compared without the fused upsampled copy only split-K ones write)
+            b.ups_y = nullptr; b.ubw_dz = nullptr;   // (candidates are compared without the fused extras only split-K ones write)
             if (i < n) { b.force_variant = cands[i].variant + 1; b.force_ksplit = cands[i].ksplit; }
             return launch_conv(b, part, cap, s);
         }, tms);
@@ -1237,6 +1237,8 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
     if (p->Sh > 0 && (rc = ready2(p->head[0].woff))) return rc;
 
     // ---- up path, last level first ----
+    const bool fuse_ups = !p->bf16 && getenv("WUN_NO_FUSE_UPS") == nullptr;
+    bool adj_done = false;
     for (int j = L - 1; j >= 0; --j) {
         const UpShape& u = p->ush[j];
         const int i = L - 1 - j;
@@ -1257,10 +1259,19 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
             a.N = u.c_skip + u.c_cur; a.N0 = u.c_skip; a.Tout = u.t_up;
             set_dst0(a, ws, p->dz_skip[i], 0, &p->skip[i]);
             set_dst1(a, ws, p->d_ups[j], 0, nullptr);
+            const Buf& prev = (j == 0) ? p->bott_out : p->upo[j - 1];
+            const Buf& dzprev = (j == 0) ? p->dz_bott : p->dz_upo[j - 1];
+            // linear interpolation: a launch that ends in the split-K epilogue kernel applies the adjoint of the 2x
+            // upsampling there (ConvArgs.ubw_*) instead of storing d_ups[j] for upsample_bwd_vec_kernel
+            if (fuse_ups && p->interp[j] < 0 && dzprev.bs == prev.bs && dzprev.pitch == prev.pitch) {
+                a.ubw_dz = ws + dzprev.off; a.ubw_x = ws + prev.off; a.ubw_bs = prev.bs; a.ubw_pitch = prev.pitch;
+                a.ubw_n = u.t_cur;
+            }
             HIP_TRY(conv_dispatch(p, a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
+            adj_done = a.ubw_dz != nullptr && conv_last_fused_ups() != 0;
             if (level_early(i)) pend_win.push_back(i);         // dz_skip[i] is final: its window input gradient can start
         }
-        {
+        if (!adj_done) {
             const Buf& prev = (j == 0) ? p->bott_out : p->upo[j - 1];
             const Buf& dzprev = (j == 0) ? p->dz_bott : p->dz_upo[j - 1];
             UpsampleBwdArgs ub;
