@@ -451,11 +451,19 @@ def main():
                 with open(os.environ["WUN_PROFILE_DETAIL"], "w") as f:
                     json.dump(prof["launches"], f)
             kernels = prof["kernels"]
+            # an event pair costs ~5 us of packet processing that is not kernel time (the library brackets nothing after
+            # every launch and reports the median): durations below are NET of it, so that they can agree with rocprofv3's
+            # kernel durations; roofline.achieved_raw_events keeps the uncorrected figure
+            ovh = float(prof.get("bracket_overhead_ms", 0.0))
+            for k in kernels:
+                k["ms_raw"] = k["ms"]
+                k["ms"] = max(k["ms"] - ovh * k["launches"], 0.05 * k["ms"])
+            log("event bracket overhead: %.2f us per launch (median empty bracket)" % (1e3 * ovh))
             kernels.sort(key=lambda k: -k["ms"])
             fam = {}
             for k in kernels:
-                f = fam.setdefault(family_of(k["name"]), {"ms": 0.0, "flops": 0.0, "launches": 0})
-                f["ms"] += k["ms"]; f["flops"] += k["flops"]; f["launches"] += k["launches"]
+                f = fam.setdefault(family_of(k["name"]), {"ms": 0.0, "ms_raw": 0.0, "flops": 0.0, "launches": 0})
+                f["ms"] += k["ms"]; f["ms_raw"] += k["ms_raw"]; f["flops"] += k["flops"]; f["launches"] += k["launches"]
                 log("  %-46s launches/step %5.1f  ms/step %8.3f  TFLOP/s %7.2f" % (
                     k["name"], k["launches"] / nprof, k["ms"] / nprof, k["flops"] / max(k["ms"], 1e-9) / 1e9))
             fams = sorted(fam.items(), key=lambda kv: -kv[1]["ms"])
@@ -469,6 +477,8 @@ def main():
                 "bound": "mfma", "kernel": top_name + " (all instantiations)", "achieved": achieved,
                 "peak": family_peak(top_name), "unit": "TFLOP/s", "frac": achieved / family_peak(top_name),
                 "traffic": pmc_traffic(top_name, table_text),
+                "event_bracket_overhead_us": 1e3 * ovh,
+                "achieved_raw_events": top["flops"] / (top["ms_raw"] * 1e-3) / 1e12,
                 "avg_launch_ms": avg_ms, "launches_per_step": top["launches"] / nprof,
                 "flops_per_launch": top["flops"] / top["launches"],
                 "family_ms_per_step": {n: f["ms"] / nprof for n, f in fams},

@@ -245,9 +245,12 @@ int wun_op_mfma_probe(const float* a, const float* b, float* d, void* stream);
 
 /* Per-kernel timing with HIP events recorded on the launch stream around every heavy launch
  * between begin and end; end() synchronises and writes a JSON summary
- * {"kernels":[{"name","launches","ms","flops"}]} (used by bench.py for the roofline line).
- * While active, the library's internal side stream is not used, so launch durations are not
- * distorted by concurrent kernels. */
+ * {"bracket_overhead_ms", "kernels":[{"name","launches","ms","flops"}]} (used by bench.py for the
+ * roofline line).  While active, the library's internal side stream is not used, so launch
+ * durations are not distorted by concurrent kernels.  "ms" is the raw sum of the event brackets;
+ * "bracket_overhead_ms" is the median duration of an EMPTY bracket recorded after every launch
+ * (two event packets cost ~5 us that are not kernel time): subtract it once per launch to compare
+ * with a profiler's kernel durations. */
 int wun_profile_begin(void);
 int wun_profile_end(char* json_out, int64_t capacity);
 

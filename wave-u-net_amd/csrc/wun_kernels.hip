@@ -25,6 +25,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 namespace wun {
@@ -42,14 +43,17 @@ __host__ __device__ static inline int fit_pitch(int width, int mod32) {
 // =====================================================================================
 // optional per-launch timing (HIP events on the launch stream), used by bench.py
 // =====================================================================================
-struct ProfSlot { std::string name; std::string tag; double flops; hipEvent_t e0, e1; };
+// Every bracket {e0, launch, e1} is followed by an EMPTY bracket {c0, c1} on the same stream: an event pair costs ~5 us of
+// packet processing that rocprofv3's kernel durations do not contain; prof_end() reports the median empty bracket so the
+// caller can state durations net of the measuring method's own cost (bench.py: roofline.event_bracket_overhead_us).
+struct ProfSlot { std::string name; std::string tag; double flops; hipEvent_t e0, e1, c0, c1; };
 static std::vector<ProfSlot> g_prof;
 static bool g_prof_on = false;
 static std::mutex g_prof_mu;
 
 void prof_begin() {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    for (auto& sl : g_prof) { (void)hipEventDestroy(sl.e0); (void)hipEventDestroy(sl.e1); }
+    for (auto& sl : g_prof) { (void)hipEventDestroy(sl.e0); (void)hipEventDestroy(sl.e1); (void)hipEventDestroy(sl.c0); (void)hipEventDestroy(sl.c1); }
     g_prof.clear();
     g_prof_on = true;
 }
@@ -60,7 +64,8 @@ struct ProfScope {
         if (!on) return;
         std::lock_guard<std::mutex> lk(g_prof_mu);
         ProfSlot sl; sl.name = name; sl.tag = tag; sl.flops = flops;
-        if (hipEventCreate(&sl.e0) != hipSuccess || hipEventCreate(&sl.e1) != hipSuccess) { on = false; return; }
+        if (hipEventCreate(&sl.e0) != hipSuccess || hipEventCreate(&sl.e1) != hipSuccess ||
+            hipEventCreate(&sl.c0) != hipSuccess || hipEventCreate(&sl.c1) != hipSuccess) { on = false; return; }
         (void)hipEventRecord(sl.e0, s);
         g_prof.push_back(sl);
         idx = g_prof.size() - 1;
@@ -69,6 +74,8 @@ struct ProfScope {
         if (!on) return;
         std::lock_guard<std::mutex> lk(g_prof_mu);
         (void)hipEventRecord(g_prof[idx].e1, s);
+        (void)hipEventRecord(g_prof[idx].c0, s);
+        (void)hipEventRecord(g_prof[idx].c1, s);
     }
 };
 
@@ -79,7 +86,8 @@ void prof_scope_begin(const char* name, double flops, hipStream_t s, const char*
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfSlot sl; sl.name = name; sl.tag = tag; sl.flops = flops;
-    if (hipEventCreate(&sl.e0) != hipSuccess || hipEventCreate(&sl.e1) != hipSuccess) return;
+    if (hipEventCreate(&sl.e0) != hipSuccess || hipEventCreate(&sl.e1) != hipSuccess ||
+        hipEventCreate(&sl.c0) != hipSuccess || hipEventCreate(&sl.c1) != hipSuccess) return;
     (void)hipEventRecord(sl.e0, s);
     g_prof.push_back(sl);
     g_prof_open = g_prof.size() - 1;
@@ -88,6 +96,8 @@ void prof_scope_end(hipStream_t s) {
     if (g_prof_open == (size_t)-1) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     (void)hipEventRecord(g_prof[g_prof_open].e1, s);
+    (void)hipEventRecord(g_prof[g_prof_open].c0, s);
+    (void)hipEventRecord(g_prof[g_prof_open].c1, s);
     g_prof_open = (size_t)-1;
 }
 
@@ -98,9 +108,11 @@ std::string prof_end() {
     struct Agg { long n = 0; double ms = 0, flops = 0; };
     std::map<std::string, Agg> agg;
     std::string detail;
+    std::vector<float> empty_ms;
     for (auto& sl : g_prof) {
-        (void)hipEventSynchronize(sl.e1);
-        float ms = 0.f;
+        (void)hipEventSynchronize(sl.c1);
+        float ms = 0.f, cms = 0.f;
+        if (hipEventElapsedTime(&cms, sl.c0, sl.c1) == hipSuccess) empty_ms.push_back(cms);
         if (hipEventElapsedTime(&ms, sl.e0, sl.e1) == hipSuccess) {
             Agg& a = agg[sl.name]; a.n += 1; a.ms += ms; a.flops += sl.flops;
             if (getenv("WUN_PROFILE_DETAIL") != nullptr) {
@@ -110,10 +122,17 @@ std::string prof_end() {
                 detail += buf;
             }
         }
-        (void)hipEventDestroy(sl.e0); (void)hipEventDestroy(sl.e1);
+        (void)hipEventDestroy(sl.e0); (void)hipEventDestroy(sl.e1); (void)hipEventDestroy(sl.c0); (void)hipEventDestroy(sl.c1);
     }
     g_prof.clear();
-    std::string out = "{\"launches\": [" + detail + "], \"kernels\": [";
+    double overhead_ms = 0.0;
+    if (!empty_ms.empty()) {
+        std::sort(empty_ms.begin(), empty_ms.end());
+        overhead_ms = empty_ms[empty_ms.size() / 2];
+    }
+    char obuf[96];
+    snprintf(obuf, sizeof(obuf), "{\"bracket_overhead_ms\": %.6f, ", overhead_ms);
+    std::string out = std::string(obuf) + "\"launches\": [" + detail + "], \"kernels\": [";
     bool first = true;
     for (auto& kv : agg) {
         char buf[512];
