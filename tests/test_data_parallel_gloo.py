@@ -169,3 +169,50 @@ def test_validation_failure_on_rank0_raises_on_every_rank(tmp_path):
     for r in (0, 1):
         got = open(os.path.join(str(tmp_path), "r%d.txt" % r)).read()
         assert "validation on rank 0 failed" in got and "checkpoint is corrupt" in got, (r, got)
+
+
+def _sharded_validation_worker(rank, world, port, out_dir, fail_rank):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    init_distributed(backend="gloo")
+    from wave_u_net_amd import validation
+    seen = []
+
+    def fake_test(model_config, partition, model_folder, load_model, tracks=None, return_sums=False, **kw):
+        assert return_sums
+        seen.extend(tracks)
+        if rank == fail_rank:
+            raise ValueError("bad track")
+        return float(sum(tracks)), len(tracks)          # one "batch" per track, its loss = the track's number
+
+    validation.test = fake_test
+    cfg = {"validation": "sharded", "log_dir": os.path.join(out_dir, "logs")}
+    try:
+        got = repr(validation._rank0_test(cfg, "valid", "x", None, [1, 2, 3, 4, 5]))
+    except RuntimeError as e:
+        got = "ERR " + str(e)
+    with open(os.path.join(out_dir, "r%d.txt" % rank), "w") as f:
+        f.write("%s|%s" % (got, seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_validation_is_the_mean_over_all_ranks_batches(tmp_path):
+    """model_config["validation"] = "sharded": rank r takes tracks[r::world]; every rank returns the same mean over all
+    batches; rank 0 writes the log line."""
+    port = _free_port()
+    mp.spawn(_sharded_validation_worker, args=(2, port, str(tmp_path), -1), nprocs=2, join=True)
+    r0 = open(os.path.join(str(tmp_path), "r0.txt")).read().split("|")
+    r1 = open(os.path.join(str(tmp_path), "r1.txt")).read().split("|")
+    assert r0[0] == r1[0] == "3.0"                            # (1+2+3+4+5) / 5
+    assert r0[1] == "[1, 3, 5]" and r1[1] == "[2, 4]"
+    line = open(os.path.join(str(tmp_path), "logs", "x", "test.jsonl")).read()
+    assert '"ranks": 2' in line and '"batches": 5' in line
+
+
+def test_sharded_validation_failure_on_any_rank_raises_on_every_rank(tmp_path):
+    port = _free_port()
+    mp.spawn(_sharded_validation_worker, args=(2, port, str(tmp_path), 1), nprocs=2, join=True)
+    for r in (0, 1):
+        got = open(os.path.join(str(tmp_path), "r%d.txt" % r)).read()
+        assert got.startswith("ERR sharded validation failed") and "rank 1: ValueError: bad track" in got, (r, got)

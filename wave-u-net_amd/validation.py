@@ -23,9 +23,11 @@ def _load_checkpoint(separator, load_model):
     return load_checkpoint(separator, load_model, with_optimizer=False)
 
 
-def test(model_config, partition, model_folder, load_model, tracks=None, data_root=None, separator=None):
+def test(model_config, partition, model_folder, load_model, tracks=None, data_root=None, separator=None,
+         return_sums=False):
     """Test.test(model_config, partition, model_folder, load_model) -> mean MSE.  The partition's
-    tracks come from `tracks` (list of track dicts) or data_root/<partition>/<track>/."""
+    tracks come from `tracks` (list of track dicts) or data_root/<partition>/<track>/.
+    return_sums: (sum of the per-batch losses, number of batches) instead, nothing logged."""
     if model_config["network"] != "unet":
         raise NotImplementedError(model_config["network"])                        # Test.py:14-19
     if tracks is None:
@@ -38,7 +40,7 @@ def test(model_config, partition, model_folder, load_model, tracks=None, data_ro
     assert (in_shape[1] - out_shape[1]) % 2 == 0                                  # Test.py:25
     global_step = _load_checkpoint(sep, load_model) if load_model is not None else 0
 
-    total_loss, batch_num = 0.0, 1
+    total_loss, batch_num, loss_sum = 0.0, 1, 0.0
     names = list(model_config["source_names"])
     for batch in datasets.get_dataset(model_config, in_shape, out_shape, partition, tracks):
         outs = sep.get_output(batch["mix"], False)                                # Test.py:34
@@ -48,7 +50,10 @@ def test(model_config, partition, model_folder, load_model, tracks=None, data_ro
             loss = loss + torch.mean((real - outs[key]) ** 2)
         curr = float(loss.item()) / float(model_config["num_sources"])
         total_loss = total_loss + (1.0 / float(batch_num)) * (curr - total_loss)  # Test.py:80
+        loss_sum += curr
         batch_num += 1
+    if return_sums:                                                               # a shard of the partition (_sharded_test)
+        return loss_sum, batch_num - 1
 
     log_dir = os.path.join(model_config["log_dir"], str(model_folder))            # Test.py:41,86-87
     os.makedirs(log_dir, exist_ok=True)
@@ -92,12 +97,51 @@ def optimise(model_config, experiment_id, data=None, data_root=None, max_epochs=
     return best_model_path, test_loss
 
 
+def _sharded_test(model_config, partition, model_folder, load_model, tracks):
+    """model_config["validation"] = "sharded": rank r evaluates tracks[r::world] and the ranks all-reduce (sum of batch
+    losses, batch count) -- no GPU idles through a validation pass and nothing waits in a broadcast for rank 0's whole
+    partition.  The loss is the mean over all ranks' batches: identical on every rank, equal to
+    test()'s for one rank, and differing from the single-process value only through where the snippet stream of a
+    shard is cut into batches (the reference weighs a short last batch like a full one too, Test.py:80).  A failure on
+    any rank is raised on every rank."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    sums, err = (0.0, 0), None
+    try:
+        mine = list(tracks)[rank::world]
+        if mine:
+            sums = test(model_config, partition, model_folder, load_model, tracks=mine, return_sums=True)
+    except Exception as e:                           # noqa: BLE001 -- re-raised below, on EVERY rank
+        err = "rank %d: %s: %s" % (rank, type(e).__name__, e)
+    errs = [None] * world
+    dist.all_gather_object(errs, err)
+    bad = [e for e in errs if e]
+    if bad:
+        raise RuntimeError("sharded validation failed: " + "; ".join(bad))
+    t = torch.tensor([float(sums[0]), float(sums[1])], dtype=torch.float64)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t)
+    if float(t[1]) == 0:
+        raise RuntimeError("sharded validation: the partition produced no batch on any rank")
+    loss = float(t[0] / t[1])
+    if rank == 0:
+        log_dir = os.path.join(model_config["log_dir"], str(model_folder))
+        os.makedirs(log_dir, exist_ok=True)
+        with open(os.path.join(log_dir, "test.jsonl"), "a") as f:
+            f.write(json.dumps({"partition": partition, "test_loss": loss, "ranks": world, "batches": int(t[1])}) + "\n")
+    return loss
+
+
 def _rank0_test(model_config, partition, model_folder, load_model, tracks):
     """test() on rank 0 only, its loss broadcast to every rank: the early-stopping decisions of
     optimise() (worse_epochs, best checkpoint, loop exit) are then identical on all ranks -- ranks
-    that disagreed would leave the next epoch's gradient all-reduce waiting forever."""
+    that disagreed would leave the next epoch's gradient all-reduce waiting forever.
+    (model_config["validation"] = "sharded" evaluates on all ranks instead: _sharded_test.)"""
     import torch.distributed as dist
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if multi and model_config.get("validation") == "sharded":
+        return _sharded_test(model_config, partition, model_folder, load_model, tracks)
     loss, err = None, None
     if not multi or dist.get_rank() == 0:
         try:
