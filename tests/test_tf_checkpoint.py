@@ -150,3 +150,30 @@ def test_reads_what_the_writer_never_emits(tmp_path):
     open(prefix + ".data-00000-of-00001", "wb").write(blob)
     back = tfc.read(prefix)
     assert np.array_equal(back["separator/a"], a) and back["separator/b"] == 5
+
+
+def test_round_trip_of_arbitrary_names_shapes_and_dtypes(tmp_path):
+    """Property test (hypothesis): whatever set of tensors is written comes back identical -- names with shared
+    prefixes (the index blocks' prefix compression), empty and scalar shapes, every dtype the reference's graph uses."""
+    hyp = pytest.importorskip("hypothesis")
+    st = pytest.importorskip("hypothesis.strategies")
+    name = st.text(alphabet="abcdefgh_/0123456789", min_size=1, max_size=40)
+    shape = st.lists(st.integers(min_value=0, max_value=5), min_size=0, max_size=3)
+    dtype = st.sampled_from([np.float32, np.int64, np.int32, np.float64])
+    counter = [0]
+
+    @hyp.settings(max_examples=40, deadline=None)
+    @hyp.given(st.dictionaries(name, st.tuples(shape, dtype, st.integers(0, 2 ** 31 - 1)), min_size=0, max_size=25))
+    def check(spec):
+        tensors = {}
+        for k, (shp, dt, seed) in spec.items():
+            rng = np.random.default_rng(seed)
+            tensors[k] = (rng.standard_normal(shp) * 100).astype(dt)
+        counter[0] += 1
+        prefix = tfc.write(tmp_path / ("p%d" % counter[0]) / "ck", tensors)
+        back = tfc.read(prefix)
+        assert sorted(back) == sorted(tensors)
+        for k, v in tensors.items():
+            assert back[k].dtype == v.dtype and back[k].shape == v.shape and np.array_equal(back[k], v), k
+
+    check()
