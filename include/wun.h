@@ -222,6 +222,12 @@ int wun_op_force_wgrad_variant(int mtw, int nw, int nsplit);
  * to bf16, v_mfma_f32_16x16x32_bf16, fp32 accumulate; same tiles / splits / reduction). */
 int wun_op_set_wgrad_bf16(int on);
 
+/* Test hook: run the following (exact-fp32) wun_op_conv1d_wgrad calls on the ping-pong form of the weight-gradient
+ * kernel (one 512-thread workgroup per CU whose two wave sets alternate between staging a unit and multiplying the
+ * previous one; same tiles, partial layout and reduction; additionally mtw = 6 with nw in {4, 5}).  Ignored while the
+ * bf16 hook is on. */
+int wun_op_set_wgrad_pp(int on);
+
 /* The bf16 speed mode's conv as a single operator (wun_op_conv1d semantics, Cin >= 8, K <= 15): operands
  * are rounded to bf16 (nearest-even), products accumulate in fp32.  scratch: device floats, at least
  * wun_op_conv1d_bf16_scratch(cin, cout, k) (packed bf16 weight image).  Synchronises the stream. */

@@ -920,8 +920,18 @@ static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const Conv
     float* out_w = grads + cl.woff;
     float* out_b = out_w + (long long)cl.KW * cl.Cin * cl.Cout;
     const size_t idx = p->wi++;
-    // default: the heuristic geometry of the largest part, lowered until every part agrees
-    {
+    // exact fp32: the register-window kernel (wun_wgrad_win.hip) where every part qualifies (15 / 5 taps, channel counts
+    // in whole row tiles); its split partials are in the final layout, so the parts need not share a tile geometry
+    static const bool no_win = getenv("WUN_NO_WIN") != nullptr;
+    bool win_ok = !no_win && !parts[0].bf16;
+    for (int i = 0; i < nparts && win_ok; ++i) { WgradArgs t = parts[i]; t.pp = 2; win_ok = wgrad_win_supported(t); }
+    auto set_win = [&](WgradArgs* q, int cgw, int nw) {
+        for (int i = 0; i < nparts; ++i) { q[i].pp = 2; q[i].force_mtw = cgw; q[i].force_nw = nw; }
+    };
+    if (win_ok) {
+        set_win(parts, 0, 0);
+    } else {
+        // default: the heuristic geometry of the largest part, lowered until every part agrees
         int m, n;
         parts[0].force_mtw = parts[0].force_nw = 0;
         wgrad_resolved_geom(parts[0], m, n);
@@ -956,10 +966,36 @@ static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const Conv
         { Cand c0; for (int i = 0; i < nparts; ++i) c0.g[i] = parts[i]; c0.c = WgradChoice{0, 0, {0, 0}}; cv.push_back(c0); }
         static const int mtws[] = {8, 6, 4, 2, 1};         // (8: bf16 kernel only; 6, 2, 1: exact-fp32 kernel only)
         WgradArgs g[2];
+        if (win_ok) {
+            // register-window kernel: column tiles per wave x split counts (choice code: mtw = 16 + column groups per workgroup)
+            const int ntile = (parts[0].N + 15) / 16;
+            int bestpad = 1 << 30;
+            for (int nw = 2; nw <= 6; ++nw) bestpad = std::min(bestpad, (ntile + nw - 1) / nw * nw);
+            for (int nw = (parts[0].KW == 15 ? 3 : 2); nw <= (parts[0].KW == 15 ? 5 : 6); ++nw) {
+                if ((ntile + nw - 1) / nw * nw > bestpad + (bestpad >= 8 ? 1 : 0) && nw != 3) continue;
+                for (int i = 0; i < nparts; ++i) g[i] = parts[i];
+                set_win(g, 1, nw);
+                int basens[2] = {0, 0}, units[2] = {0, 0};
+                for (int i = 0; i < nparts; ++i) { basens[i] = wgrad_pick_nsplit(g[i]); units[i] = wgrad_max_units(g[i]); }
+                static const int num[5] = {4, 2, 6, 8, 3};          // split factor / 4: 1, 1/2, 3/2, 2, 3/4
+                for (int oi = 0; oi < 5; ++oi) {
+                    for (int i = 0; i < nparts; ++i) {
+                        int ns = basens[i] * num[oi] / 4;
+                        if (ns < 1) ns = 1;
+                        if (ns > units[i]) ns = units[i];
+                        g[i].nsplit = ns;
+                    }
+                    Cand c;
+                    for (int i = 0; i < nparts; ++i) c.g[i] = g[i];
+                    c.c = WgradChoice{17, nw, {g[0].nsplit, nparts > 1 ? g[1].nsplit : 0}};
+                    cv.push_back(c);
+                }
+            }
+        }
         for (int mi = 0; mi < 5; ++mi)
             for (int nw = 5; nw >= 1; --nw) {
                 if (nw > 3 && (mtws[mi] == 6 || parts[0].N <= 48)) continue;
-                for (int i = 0; i < nparts; ++i) g[i] = parts[i];
+                for (int i = 0; i < nparts; ++i) { g[i] = parts[i]; g[i].pp = 0; }
                 if (!wgrad_common_geom(g, nparts, mtws[mi], nw)) continue;
                 int m, n;
                 wgrad_resolved_geom(g[0], m, n);
@@ -1013,11 +1049,18 @@ static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const Conv
     }
     if (p->tune_mode >= 1 && idx < p->wg_bwd.size() && p->wg_bwd[idx].nsplit[0] > 0) {
         const WgradChoice& c = p->wg_bwd[idx];
-        bool ok = (c.mtw == 1 || c.mtw == 2 || c.mtw == 4 || c.mtw == 6 || c.mtw == 8) && c.nw >= 1 && c.nw <= 5;
+        const bool cwin = c.mtw == 17;
+        bool ok = cwin ? (win_ok && c.nw >= 1 && c.nw <= 6)
+                       : ((c.mtw == 1 || c.mtw == 2 || c.mtw == 4 || c.mtw == 6 || c.mtw == 8) && c.nw >= 1 && c.nw <= 5);
         for (int i = 0; ok && i < nparts; ++i) ok = c.nsplit[i] >= 1;
         WgradArgs g[2];
-        for (int i = 0; i < nparts; ++i) g[i] = parts[i];
-        if (ok && wgrad_common_geom(g, nparts, c.mtw, c.nw)) {
+        for (int i = 0; i < nparts; ++i) { g[i] = parts[i]; g[i].pp = 0; }
+        if (ok && cwin) {
+            set_win(g, 1, c.nw);
+            for (int i = 0; ok && i < nparts; ++i) ok = c.nsplit[i] <= wgrad_max_units(g[i]);
+            if (ok)
+                for (int i = 0; i < nparts; ++i) { parts[i] = g[i]; parts[i].nsplit = c.nsplit[i]; }
+        } else if (ok && wgrad_common_geom(g, nparts, c.mtw, c.nw)) {
             for (int i = 0; ok && i < nparts; ++i) ok = c.nsplit[i] <= wgrad_max_units(g[i]);
             if (ok)
                 for (int i = 0; i < nparts; ++i) { parts[i] = g[i]; parts[i].nsplit = c.nsplit[i]; }
@@ -1431,7 +1474,7 @@ extern "C" int wun_plan_tune(const wun_plan* p, const float* params, const float
 // Tuning-table header: identifies the plan (every config key that changes a launch), the launch
 // order of this library build and the number of entries per section, so a table written for
 // another plan, another library build or truncated on disk is rejected at import.
-#define WUN_TUNE_ORDER "r3c"      /* bump whenever the order / number of conv or wgrad launches changes */
+#define WUN_TUNE_ORDER "r4a"      /* bump whenever the order / number of conv or wgrad launches changes */
 static std::string tune_header(const wun_plan* p, size_t ncf, size_t ncb, size_t nwg) {
     char line[320];
     const wun_config& c = p->cfg;
@@ -1501,7 +1544,7 @@ extern "C" int wun_plan_tune_import(const wun_plan* p, const char* text) {
                 c.ksplit < 0 || c.ksplit > 64)
                 return fail(WUN_ERR_INVALID, "tuning table entry out of range");
     for (const WgradChoice& c : wg)
-        if (c.nsplit[0] < 0 || c.nsplit[1] < 0 || c.mtw < 0 || c.mtw > 8 || c.nw < 0 || c.nw > 5)
+        if (c.nsplit[0] < 0 || c.nsplit[1] < 0 || c.mtw < 0 || (c.mtw > 8 && c.mtw != 17) || c.nw < 0 || c.nw > 6)
             return fail(WUN_ERR_INVALID, "tuning table entry out of range");
     // (whether each entry is a legal choice for the launch at its position is checked when it is used)
     p->conv_fwd = cf; p->conv_bwd = cb; p->wg_bwd = wg;
@@ -1528,6 +1571,7 @@ static const long long kOpScratchFloats = 8ll << 20;
 static int g_op_variant = -1, g_op_ksplit = 0;          // wun_op_force_conv_variant (test hook)
 static int g_op_wg_mtw = 0, g_op_wg_nw = 0, g_op_wg_nsplit = 0;   // wun_op_force_wgrad_variant (test hook)
 static int g_op_wg_bf16 = 0;                                       // wun_op_set_wgrad_bf16 (test hook)
+static int g_op_wg_pp = 0;                                         // wun_op_set_wgrad_pp (test hook)
 static float* op_scratch() {
     static float* buf = nullptr;
     if (!buf && hipMalloc((void**)&buf, kOpScratchFloats * sizeof(float)) != hipSuccess) {
@@ -1581,9 +1625,12 @@ static WgradArgs op_wgrad_args(const float* x, const float* dz, int batch, int c
 static long long op_wgrad_part_floats(int batch, int cin, int cout, int k, int t_out, int loader) {
     WgradArgs a = wgrad_shape_only(batch, cin, 0, k, loader, cout, t_out);
     a.bf16 = (g_op_wg_bf16 && wgrad_bf16_supported(a)) ? 1 : 0;
+    a.pp = (g_op_wg_pp && !a.bf16) ? g_op_wg_pp : 0;
+    if (a.pp == 2 && !wgrad_win_supported(a)) a.pp = 0;
     if (g_op_wg_mtw > 0) { a.force_mtw = g_op_wg_mtw; a.force_nw = g_op_wg_nw; }
     long long ns = wgrad_pick_nsplit(a);
     if (g_op_wg_nsplit > 0) ns = std::min(g_op_wg_nsplit, wgrad_max_units(a));
+    if (g_op_wg_nsplit < 0 && a.pp == 2) ns = std::min(std::max(1, -g_op_wg_nsplit / wgrad_win_tiles(a)), wgrad_max_units(a));
     return ns * wgrad_partial_floats(a);
 }
 
@@ -1615,6 +1662,8 @@ extern "C" int wun_op_conv1d_wgrad(const float* x, const float* dz, float* dw, f
     WgradArgs w = op_wgrad_args(xs, zs, batch, cin, cout, k, t_in, t_out, stride, pad_left, xp, zp);
     if (g_op_wg_bf16 && !wgrad_bf16_supported(w)) return fail(WUN_ERR_UNSUPPORTED, "shape not served by the bf16 weight-gradient kernel");
     w.bf16 = g_op_wg_bf16;
+    w.pp = (g_op_wg_pp && !w.bf16) ? g_op_wg_pp : 0;
+    if (w.pp == 2 && !wgrad_win_supported(w)) return fail(WUN_ERR_UNSUPPORTED, "shape not served by the register-window weight-gradient kernel");
     if (g_op_wg_mtw > 0) {
         w.force_mtw = g_op_wg_mtw; w.force_nw = g_op_wg_nw;
         int m, n;
@@ -1626,6 +1675,8 @@ extern "C" int wun_op_conv1d_wgrad(const float* x, const float* dz, float* dw, f
     if (g_op_wg_nsplit > 0) {
         w.nsplit = std::min(g_op_wg_nsplit, wgrad_max_units(w));
     }
+    if (g_op_wg_nsplit < 0 && w.pp == 2)       // (window kernel: a negative count is a target grid size)
+        w.nsplit = std::min(std::max(1, -g_op_wg_nsplit / wgrad_win_tiles(w)), wgrad_max_units(w));
     part = (float*)(((uintptr_t)part + 255) & ~(uintptr_t)255);
     w.out = part; w.direct = 0; w.split_base = 0;      // always through the split reduction (dw and db are separate buffers)
     HIP_TRY(launch_wgrad(w, s));
@@ -1692,6 +1743,7 @@ extern "C" int wun_op_force_conv_variant(int variant, int ksplit) {
 extern "C" int wun_op_num_conv_variants(void) { return conv_num_variants(); }
 
 extern "C" int wun_op_set_wgrad_bf16(int on) { g_op_wg_bf16 = on ? 1 : 0; return WUN_OK; }
+extern "C" int wun_op_set_wgrad_pp(int mode) { g_op_wg_pp = (mode == 1 || mode == 2) ? mode : 0; return WUN_OK; }
 
 extern "C" int wun_op_force_wgrad_variant(int mtw, int nw, int nsplit) {
     g_op_wg_mtw = mtw; g_op_wg_nw = nw; g_op_wg_nsplit = nsplit;
