@@ -40,6 +40,7 @@ import torch         # noqa: E402
 import torch.distributed as dist   # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA = fp32 vector peak
+PEAK_HBM_GBPS = 8000.0             # same guide: HBM3E 8 TB/s spec (a float4 copy reaches 6.3 TB/s)
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide: dense bf16 MFMA (the 5 PF headline figure includes 2:1 sparsity)
 
 
@@ -486,6 +487,14 @@ def main():
                 "family_launches_per_step": {n: f["launches"] / nprof for n, f in fams},
                 "kernel_ms_per_step": {k["name"]: k["ms"] / nprof for k in kernels},
                 "kernel_tflops": {k["name"]: k["flops"] / (k["ms"] * 1e-3) / 1e12 for k in kernels if k["ms"] > 0},
+                # the bandwidth-bound kernels against the HBM roof (north_star: "achieved fraction of HBM roofline"):
+                # ALGORITHMIC bytes (what a perfect implementation must move: DESIGN.md section 5) / launch time by the same
+                # HIP-event brackets; frac of the 8 TB/s the microarchitecture guide quotes (6.3 TB/s is what a copy reaches)
+                "hbm": {k["name"]: {"GBps": k["bytes"] / (k["ms"] * 1e-3) / 1e9, "frac": k["bytes"] / (k["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                                    "bytes_per_launch": k["bytes"] / k["launches"], "us_per_launch": 1e3 * k["ms"] / k["launches"],
+                                    "launches_per_step": k["launches"] / nprof}
+                        for k in kernels if k.get("bytes", 0) > 0 and k["ms"] > 0},
+                "hbm_peak_GBps": PEAK_HBM_GBPS,
             }
 
     if gpu0 is not None:

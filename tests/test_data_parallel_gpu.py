@@ -94,5 +94,27 @@ def test_bench_launches_itself_two_ranks_on_one_gpu():
     assert len(lines) == 1, r.stdout
     d = lines[0]
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 4 and d["config"]["global_batch"] == 6
+    assert d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and d["ms_p10"] <= d["ms_median"] <= d["ms_p90"]
+    assert np.isfinite(d["config"]["final_loss"])
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_headline_config_reduced_width():
+    """The driver's multi-GPU command on the headline configuration's wiring (M1 + context, reduced to 4 levels / 8
+    filters so two ranks fit one GPU in seconds): `python bench.py --gpus 2 --config m1_context ...` end to end --
+    self-launch under torch.distributed.run, tuning-table broadcast, bucketed gradient exchange, one JSON line."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(WUN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "m1_context",
+           "--set", "num_layers=4", "--set", "num_initial_filters=8", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3
+    assert d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 32
+    assert d["metric"].startswith("waveform samples/sec") and d["value"] > 0
     assert np.isfinite(d["config"]["final_loss"])

@@ -219,7 +219,7 @@ hipError_t launch_fill(float* p, long long n, float val, hipStream_t s);
 hipError_t launch_mfma_probe(const float* a, const float* b, float* d, hipStream_t s);
 void prof_begin();
 std::string prof_end();
-void prof_scope_begin(const char* name, double flops, hipStream_t s, const char* tag);   // HIP-event bracket of the next launch
+void prof_scope_begin(const char* name, double flops, hipStream_t s, const char* tag, double bytes = 0.0);   // HIP-event bracket of the next launch (bytes: algorithmic HBM bytes of a bandwidth-bound launch)
 void prof_scope_end(hipStream_t s);
 
 // ---- narrow weight gradients (wun_narrow.hip) ----

@@ -46,7 +46,7 @@ __host__ __device__ static inline int fit_pitch(int width, int mod32) {
 // Every bracket {e0, launch, e1} is followed by an EMPTY bracket {c0, c1} on the same stream: an event pair costs ~5 us of
 // packet processing that rocprofv3's kernel durations do not contain; prof_end() reports the median empty bracket so the
 // caller can state durations net of the measuring method's own cost (bench.py: roofline.event_bracket_overhead_us).
-struct ProfSlot { std::string name; std::string tag; double flops; hipEvent_t e0, e1, c0, c1; };
+struct ProfSlot { std::string name; std::string tag; double flops; double bytes; hipEvent_t e0, e1, c0, c1; };
 static std::vector<ProfSlot> g_prof;
 static bool g_prof_on = false;
 static std::mutex g_prof_mu;
@@ -60,10 +60,11 @@ void prof_begin() {
 
 struct ProfScope {
     bool on; hipStream_t s; size_t idx;
-    ProfScope(const char* name, double flops, hipStream_t st, const char* tag = "") : on(g_prof_on), s(st), idx(0) {
+    // bytes: ALGORITHMIC HBM bytes of a bandwidth-bound launch (what a perfect implementation must move), 0 for MFMA kernels
+    ProfScope(const char* name, double flops, hipStream_t st, const char* tag = "", double bytes = 0.0) : on(g_prof_on), s(st), idx(0) {
         if (!on) return;
         std::lock_guard<std::mutex> lk(g_prof_mu);
-        ProfSlot sl; sl.name = name; sl.tag = tag; sl.flops = flops;
+        ProfSlot sl; sl.name = name; sl.tag = tag; sl.flops = flops; sl.bytes = bytes;
         if (hipEventCreate(&sl.e0) != hipSuccess || hipEventCreate(&sl.e1) != hipSuccess ||
             hipEventCreate(&sl.c0) != hipSuccess || hipEventCreate(&sl.c1) != hipSuccess) { on = false; return; }
         (void)hipEventRecord(sl.e0, s);
@@ -81,11 +82,11 @@ struct ProfScope {
 
 // explicit begin / end form for launchers in other translation units (one bracket at a time)
 static size_t g_prof_open = (size_t)-1;
-void prof_scope_begin(const char* name, double flops, hipStream_t s, const char* tag) {
+void prof_scope_begin(const char* name, double flops, hipStream_t s, const char* tag, double bytes) {
     g_prof_open = (size_t)-1;
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    ProfSlot sl; sl.name = name; sl.tag = tag; sl.flops = flops;
+    ProfSlot sl; sl.name = name; sl.tag = tag; sl.flops = flops; sl.bytes = bytes;
     if (hipEventCreate(&sl.e0) != hipSuccess || hipEventCreate(&sl.e1) != hipSuccess ||
         hipEventCreate(&sl.c0) != hipSuccess || hipEventCreate(&sl.c1) != hipSuccess) return;
     (void)hipEventRecord(sl.e0, s);
@@ -105,7 +106,7 @@ void prof_scope_end(hipStream_t s) {
 std::string prof_end() {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_on = false;
-    struct Agg { long n = 0; double ms = 0, flops = 0; };
+    struct Agg { long n = 0; double ms = 0, flops = 0, bytes = 0; };
     std::map<std::string, Agg> agg;
     std::string detail;
     std::vector<float> empty_ms;
@@ -114,7 +115,7 @@ std::string prof_end() {
         float ms = 0.f, cms = 0.f;
         if (hipEventElapsedTime(&cms, sl.c0, sl.c1) == hipSuccess) empty_ms.push_back(cms);
         if (hipEventElapsedTime(&ms, sl.e0, sl.e1) == hipSuccess) {
-            Agg& a = agg[sl.name]; a.n += 1; a.ms += ms; a.flops += sl.flops;
+            Agg& a = agg[sl.name]; a.n += 1; a.ms += ms; a.flops += sl.flops; a.bytes += sl.bytes;
             if (getenv("WUN_PROFILE_DETAIL") != nullptr) {
                 char buf[512];
                 snprintf(buf, sizeof(buf), "%s{\"name\": \"%s\", \"tag\": \"%s\", \"ms\": %.6f, \"flops\": %.6e}",
@@ -136,8 +137,8 @@ std::string prof_end() {
     bool first = true;
     for (auto& kv : agg) {
         char buf[512];
-        snprintf(buf, sizeof(buf), "%s{\"name\": \"%s\", \"launches\": %ld, \"ms\": %.6f, \"flops\": %.6e}",
-                 first ? "" : ", ", kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.flops);
+        snprintf(buf, sizeof(buf), "%s{\"name\": \"%s\", \"launches\": %ld, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
+                 first ? "" : ", ", kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.flops, kv.second.bytes);
         out += buf;
         first = false;
     }
@@ -1331,7 +1332,13 @@ static hipError_t conv_launch_t(ConvArgs a, int variant, float* part, long long 
     const long long total = (long long)a.B * a.N * (((a.Tout + 3) & ~3) >> 2);
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, ksplit);
+    {
+        const double elems = (double)a.B * a.N * a.Tout;
+        double by = 4.0 * elems * (ksplit + 1 + (a.msk0 != nullptr ? 1 : 0) + ((a.flags & F_ACCUM) ? 1 : 0));
+        if (a.ups_y != nullptr) by += 4.0 * (double)a.B * a.N * a.ups_tup;
+        ProfScope ps("conv_splitk_epilogue_kernel", 0.0, s, "", by);
+        hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, ksplit);
+    }
     t_last_fused_ups = (a.ups_y != nullptr || a.ubw_dz != nullptr) ? 1 : 0;
     return hipGetLastError();
 }
@@ -2048,7 +2055,7 @@ hipError_t launch_wgrad_reduce(const WgradArgs& a, const float* partial, int nsp
     const long long blocks = (slots + vpb - 1) / vpb;
     char tag[96];
     snprintf(tag, sizeof(tag), "bytes=%lld nsplit=%d", (long long)((nsplit + 1) * slots * 16), nsplit);
-    ProfScope ps("wgrad_reduce_kernel", 0.0, s, tag);
+    ProfScope ps("wgrad_reduce_kernel", 0.0, s, tag, (double)((nsplit + 1) * slots * 16));
     if (sl == 16) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, r);
     else if (sl == 4) hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, r);
     else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, r);
@@ -2116,6 +2123,7 @@ __global__ __launch_bounds__(256) void upsample_vec_kernel(UpsampleArgs a) {
 }
 
 hipError_t launch_upsample(const UpsampleArgs& a, hipStream_t s) {
+    ProfScope ps("upsample_kernel", 0.0, s, "", 4.0 * (double)a.B * a.C * ((double)a.n + a.tup));
     if ((a.ypitch & 3) == 0 && (a.ybs & 3) == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0 && (long long)a.B * a.C <= 4 * 65535ll) {
         const int nvec = (a.tup + 3) / 4;
         hipLaunchKernelGGL(upsample_vec_kernel, dim3((unsigned)((nvec + 63) / 64), (unsigned)((a.B * a.C + 3) / 4)), dim3(256), 0, s, a);
@@ -2227,6 +2235,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_vec_kernel(UpsampleBwdArgs a
 }
 
 hipError_t launch_upsample_bwd(const UpsampleBwdArgs& a, hipStream_t s) {
+    ProfScope ps("upsample_bwd_kernel", 0.0, s, "", 4.0 * (double)a.B * a.C * (2.0 * a.n + a.tup));
     const long long total = (long long)a.B * a.C * a.n;
     long long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
@@ -2420,6 +2429,7 @@ hipError_t launch_btc_to_ncw(const float* src, float* dst, int B, int T, int C, 
     const long long total = (long long)B * T * C;
     long long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
+    ProfScope ps("btc_to_ncw_kernel", 0.0, s, "", 8.0 * (double)total);
     hipLaunchKernelGGL(btc_to_ncw_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, B, T, C, pitch);
     return hipGetLastError();
 }
@@ -2530,6 +2540,7 @@ hipError_t launch_adam(float* p, const float* g, float* m, float* v, long long n
                        float b1, float b2, float eps, float gscale, hipStream_t s) {
     long long blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
+    ProfScope ps("adam_kernel", 0.0, s, "", 28.0 * (double)n);       // p, m, v read + written, g read
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, n, lr_t, b1, b2,
                        eps, gscale);
     return hipGetLastError();
@@ -2572,6 +2583,8 @@ hipError_t launch_head_fwd_off(const HeadArgs& a, const long long* hoff, hipStre
     const long long total = (long long)a.B * a.Tout;
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
+    // feature map + mix window read once, all sources written
+    ProfScope ps("head_fwd_kernel", 0.0, s, "", 4.0 * (double)a.B * ((double)a.Tfeat * (a.F + a.C) + (double)a.Tout * a.S * a.C));
     hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)blocks), dim3(256), head_lds(a), s, a, hoff[0],
                        hoff[1], hoff[2], hoff[3]);
     return hipGetLastError();
@@ -2585,9 +2598,14 @@ int head_bwd_blocks(const HeadArgs& a) {
 }
 
 hipError_t launch_head_bwd_off(const HeadArgs& a, const long long* hoff, hipStream_t s) {
-    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)head_bwd_blocks(a)), dim3(256), 0, s, a);
+    {
+        // outputs + targets read, d(pre-activation) written
+        ProfScope ps("head_bwd_kernel", 0.0, s, "", 4.0 * (double)a.B * a.Tout * a.C * (2.0 * a.S + a.Sh));
+        hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)head_bwd_blocks(a)), dim3(256), 0, s, a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    ProfScope ps("head_dfeat_kernel", 0.0, s, "", 4.0 * (double)a.B * ((double)a.Tout * a.Sh * a.C + (double)a.Tfeat * a.F));
     const long long total = (long long)a.B * a.Tfeat;
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;

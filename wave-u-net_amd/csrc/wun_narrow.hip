@@ -216,7 +216,9 @@ hipError_t launch_narrow_wgrad(NarrowWgradArgs a, hipStream_t s) {
     const int KT = narrow_kt(a.KW);
     char tag[160];
     snprintf(tag, sizeof(tag), "C=%d N=%d T=%d K=%d stride=%d B=%d nsplit=%d", a.C0 + a.C1, a.N, a.Tq, a.KW, a.stride, a.B, a.nsplit);
-    prof_scope_begin("narrow_wgrad_kernel", 2.0 * a.KW * (double)(a.C0 + a.C1) * a.N * (double)a.Tq * a.B, s, tag);
+    // (bandwidth-bound: dz rows + the input rows they touch streamed once)
+    prof_scope_begin("narrow_wgrad_kernel", 2.0 * a.KW * (double)(a.C0 + a.C1) * a.N * (double)a.Tq * a.B, s, tag,
+                     4.0 * (double)a.B * a.Tq * ((double)a.N + (double)(a.C0 + a.C1) * a.stride));
 #define WUN_NWL(K, S) \
     if (KT == K && a.stride == S) { \
         auto kern = narrow_wgrad_kernel<K, S>; \

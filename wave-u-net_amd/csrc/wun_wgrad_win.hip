@@ -123,6 +123,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((K15 ? NW <
     // scalar-base form, no address VALU, no exec masks (interior units of single-source tiles; the other units clamp
     // per lane, below).  Slot f of a region lands at LDS float 4 f (lane-linear).
     unsigned xb[WUN_WIN_XIT], zbo[WUN_WIN_ZIT];
+    unsigned xs1 = 0;                                   // bit i: slot i of this thread reads the second source
     const float inv_xg = 1.0f / (float)XG, inv_zg = 1.0f / (float)ZG;
     // slot -> (row, granule) of the X / dz region
     auto xslot = [&](int f, int& row, int& g) __attribute__((always_inline)) {
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((K15 ? NW <
         bool s1;
         const int ro = xrow_src(row < nXrows ? row : nXrows - 1, s1);
         xb[i] = 4u * (unsigned)(ro + 4 * (g < p.XGL ? g : p.XGL - 1));
+        xs1 |= (s1 ? 1u : 0u) << i;
     }
 #pragma unroll
     for (int i = 0; i < WUN_WIN_ZIT; ++i) {
@@ -186,18 +188,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((K15 ? NW <
         return (shift_edge && qt == 0) || t0 + t4 > a.Tin || q0 + p.TK > a.Tq;
     };
     // one unit = p.TK output positions of one excerpt
-    auto unit_fast = [&](int qt) __attribute__((always_inline)) { return one_src && !unit_edge(qt); };
+    auto unit_fast = [&](int qt) __attribute__((always_inline)) { return !unit_edge(qt); };
     // interior unit of a single-source tile
     auto dma_fast = [&](int b, int qt, int bo) __attribute__((always_inline)) {
         const int q0 = qt * p.TK;
         const int t0 = S * q0 - a.shift;                 // time index of the first staged sample
         {
-            const float* xbs = win_sgpr_ptr(tile_s1 ? a.src1 + (long long)b * a.bs1 + a.off1 + t0
-                                                    : a.src0 + (long long)b * a.bs0 + a.off0 + t0);
             const unsigned m0x = win_sgpr(m0w + 4u * (unsigned)bo);
+            if (one_src) {
+                const float* xbs = win_sgpr_ptr(tile_s1 ? a.src1 + (long long)b * a.bs1 + a.off1 + t0
+                                                        : a.src0 + (long long)b * a.bs0 + a.off0 + t0);
 #pragma unroll
-            for (int i = 0; i < WUN_WIN_XIT; ++i)
-                if (i < nxi) win_dma16(m0x + (unsigned)i * nthr16, xb[i], xbs);
+                for (int i = 0; i < WUN_WIN_XIT; ++i)
+                    if (i < nxi) win_dma16(m0x + (unsigned)i * nthr16, xb[i], xbs);
+            } else {
+                // the tile straddles the two sources of a channel concat: every instruction once per source, lanes split
+                const float* xb0 = win_sgpr_ptr(a.src0 + (long long)b * a.bs0 + a.off0 + t0);
+                const float* xb1 = win_sgpr_ptr(a.src1 + (long long)b * a.bs1 + a.off1 + t0);
+#pragma unroll
+                for (int i = 0; i < WUN_WIN_XIT; ++i)
+                    if (i < nxi) {
+                        if ((xs1 >> i) & 1u) win_dma16(m0x + (unsigned)i * nthr16, xb[i], xb1);
+                        else win_dma16(m0x + (unsigned)i * nthr16, xb[i], xb0);
+                    }
+            }
             const float* zbs = win_sgpr_ptr(a.dz + (long long)b * a.dzbs + q0);
             const unsigned m0z = win_sgpr(m0w + 4u * (unsigned)(bo + zoff));
 #pragma unroll
@@ -690,7 +704,7 @@ hipError_t launch_wgrad_win_reduce(const WgradArgs& a, const float* partial, int
     const long long n4 = (n + 3) / 4;
     char tag[96];
     snprintf(tag, sizeof(tag), "bytes=%lld nsplit=%d", (long long)(nsplit + 1) * n * 4, nsplit);
-    prof_scope_begin("wgrad_win_reduce_kernel", 0.0, s, tag);
+    prof_scope_begin("wgrad_win_reduce_kernel", 0.0, s, tag, (double)(nsplit + 1) * (double)n * 4.0);
     const int sl = nsplit >= 128 ? 16 : (nsplit >= 16 ? 4 : 1);
     const int vpb = 256 / sl;
     const long long blocks = (n4 + vpb - 1) / vpb;
