@@ -75,7 +75,41 @@ def main():
     masks = [(p.double() > 0) for p in pre32]
     _, g64m, _ = run(torch.float64, force=masks)
     dm = dev(g64m)
+    # the pre-activations nearest to zero (relative to their layer's mean magnitude): flip ONE mask bit each, float64
+    # arithmetic otherwise -- the size of the gradient change a single sign decision carries
+    cands = []
+    for li_, a in enumerate(pre64):
+        flat = a.contiguous().abs().flatten()
+        v, idx = torch.topk(flat, 1, largest=False)
+        cands.append((float(v[0] / a.abs().mean()), li_, int(idx[0])))
+    cands.sort()
+    base_masks = [(p > 0) for p in pre64]
+    single = []
+    for relmag, li_, idx in cands[:4]:
+        masks1 = [m.contiguous().clone() for m in base_masks]
+        flat = masks1[li_].view(-1)
+        flat[idx] = ~flat[idx]
+        _, g1, _ = run(torch.float64, force=masks1)
+        d1 = dev(g1)
+        single.append({"leaky_relu_index": li_, "shape": list(pre64[li_].shape), "|x|_over_layer_mean": relmag,
+                       "worst": [{"tensor": n, "max_err_over_max_ref": a, "rel_l2": b} for a, b, n in d1[:4]]})
+    # float32 oracle under last-bit input perturbations (the float64 reference re-computed on the SAME perturbed input):
+    # how far does a float32 evaluation of the reference arithmetic itself jump?
+    rng = np.random.default_rng(5)
+    perturbed = []
+    for t in range(7):
+        m = (mix * (1.0 + 3e-7 * rng.standard_normal(mix.shape))).astype(np.float32)
+        def run_on(dtype):
+            tp = wt.params_to_torch(params, dtype, requires_grad=True)
+            _, grads = wt.train_step(ocfg, tp, torch.tensor(m, dtype=dtype), {k: torch.tensor(v, dtype=dtype) for k, v in targets.items()})
+            return [g.double() for g in grads]
+        r64, r32 = run_on(torch.float64), run_on(torch.float32)
+        rows = sorted([((a - b).abs().max().item() / max(b.abs().max().item(), 1e-30), n) for n, a, b in zip(names, r32, r64)], reverse=True)
+        perturbed.append({"perturbation": t + 1, "worst": [{"tensor": n, "max_err_over_max_ref": e} for e, n in rows[:3]],
+                          "tensors_above_1e-5": sum(1 for e, _ in rows if e > 1e-5)})
     res = {
+        "float32_oracle_vs_float64_under_3e-7_input_perturbations": perturbed,
+        "single_mask_flips_of_the_inputs_nearest_zero": single,
         "config": "M1 + context, B=%d, %d -> %d samples, golden_params seed 77, synthetic_batch seed 78" % (B, i[1], o[1]),
         "leaky_relu_inputs": total, "sign_differs_float32_vs_float64": flips, "per_layer": per_layer,
         "largest_|x|_of_a_flipped_input_over_mean|x|": max(tiny) if tiny else 0.0,

@@ -1238,6 +1238,7 @@ static inline long long conv_mtiles(const ConvArgs& a, int variant, int TT, int&
 }
 
 size_t conv_lds_bytes(const ConvArgs& a, int variant) {
+    if (variant >= WUN_FIRST_WIN_VARIANT) return conv_win_lds_bytes(a, variant - WUN_FIRST_WIN_VARIANT);
     int TT, NT, J, XP, WP;
     conv_geom(a, variant, TT, NT, J, XP, WP);
     const int CK = kConvVariants[variant].CK;
@@ -1349,6 +1350,7 @@ static hipError_t conv_launch_t(ConvArgs a, int variant, float* part, long long 
 // past the partial scratch or select a tile the loader does not support).
 bool conv_choice_ok(const ConvArgs& a, long long part_cap, int v, int ks) {
     const int nvar = (int)(sizeof(kConvVariants) / sizeof(kConvVariants[0]));
+    if (v >= WUN_FIRST_WIN_VARIANT) return ks == 1 && conv_win_ok(a, v - WUN_FIRST_WIN_VARIANT);     // register-window tiles
     if (v < 0 || v >= nvar || ks < 1) return false;
     const int Ctot = a.C0 + a.C1;
     const bool phase2 = (a.flags & F_PHASE2) != 0;
@@ -1377,7 +1379,7 @@ bool conv_choice_ok(const ConvArgs& a, long long part_cap, int v, int ks) {
 // Candidate (tile variant, split-K) choices for the autotuner.  Returns the number written.
 int conv_list_candidates(const ConvArgs& a, long long part_cap, ConvChoice* out, int maxn) {
     int n = 0;
-    const int nvar = (int)(sizeof(kConvVariants) / sizeof(kConvVariants[0]));
+    const int nvar = conv_num_variants();
     static const int ks_menu[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48};
     for (int v = 0; v < nvar && n < maxn; ++v)
         for (unsigned i = 0; i < sizeof(ks_menu) / sizeof(ks_menu[0]) && n < maxn; ++i) {
@@ -1387,7 +1389,8 @@ int conv_list_candidates(const ConvArgs& a, long long part_cap, ConvChoice* out,
     return n;
 }
 
-int conv_num_variants() { return (int)(sizeof(kConvVariants) / sizeof(kConvVariants[0])); }
+static_assert(sizeof(kConvVariants) / sizeof(kConvVariants[0]) == WUN_FIRST_WIN_VARIANT, "window variants follow the tile table");
+int conv_num_variants() { return WUN_FIRST_WIN_VARIANT + conv_win_num_variants(); }
 
 
 int conv_last_fused_ups() { return t_last_fused_ups; }
@@ -1432,7 +1435,13 @@ hipError_t launch_conv(const ConvArgs& a_in, float* part, long long part_cap, hi
     if (a.force_variant > 0 && vecw) {
         v = a.force_variant - 1;
         if (!conv_choice_ok(a, part != nullptr ? part_cap : 0, v, a.force_ksplit > 0 ? a.force_ksplit : 1)) return hipErrorInvalidValue;
+    } else if (vecw && a.Wwin != nullptr) {
+        // heuristic: a register-window tile where the launch qualifies and fills the chip without split-K
+        static const bool win_default = getenv("WUN_CONV_WIN_DEFAULT") == nullptr || atoi(getenv("WUN_CONV_WIN_DEFAULT")) != 0;
+        const int wv = win_default ? conv_win_pick(a) : -1;
+        if (wv >= 0 && (long long)a.B * ((a.Tout + 255) / 256) * ((a.N + 47) / 48) >= 256) v = WUN_FIRST_WIN_VARIANT + wv;
     }
+    if (v >= WUN_FIRST_WIN_VARIANT) return launch_conv_win(a, v - WUN_FIRST_WIN_VARIANT, s);
 #ifdef WUN_ABLATION
     if (const char* e = getenv("WUN_VARIANT")) v = atoi(e);
 #endif

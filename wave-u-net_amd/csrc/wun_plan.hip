@@ -152,6 +152,13 @@ struct wun_plan {
     int npack_fwd = 0;
     long long pack_max = 0;
     PackDesc* dev_pack = nullptr;
+    // exact fp32: "window layout" copies [C][ceil(K/4)][N][4] of the conv weights for the register-window conv kernel
+    // (wun_conv_win.hip), keyed like bf_img; forward weights first, then the stride-1 input-gradient weights
+    std::map<std::pair<int, long long>, long long> win_img;  // (1 = in workspace, float offset) -> float offset of the copy
+    std::vector<WinPackDesc> winp;
+    int nwinp_fwd = 0;
+    long long winp_max = 0;
+    WinPackDesc* dev_winp = nullptr;
     mutable const float* cur_params = nullptr;
     mutable const float* cur_ws = nullptr;
 };
@@ -340,6 +347,28 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
     p->bott.wt_full = add_wt(p->bott, Kd, Kd - 1, 1);
     for (int j = 0; j < L; ++j) p->up[j].wt_full = add_wt(p->up[j], Ku, Ku - 1, 1);
 
+    // ---- exact fp32: window-layout copies for the register-window conv kernel (15- and 5-tap convs, >= 8 input channels) ----
+    if (cfg->compute_dtype != 1 && getenv("WUN_NO_CONV_WIN") == nullptr) {
+        auto add_win = [&](int in_ws, long long src_off, int K, int Cin, int Nout) {
+            if (!(K == 15 || K == 5) || Cin < 8 || (Cin & 3) || (Nout & 3) || Nout < 16) return;
+            WinPackDesc d;
+            d.src_off = src_off; d.K = K; d.C = Cin; d.N = Nout; d.src_in_ws = in_ws;
+            const long long vecs = (long long)Cin * ((K + 3) / 4) * Nout;
+            d.dst_off = bump(w, vecs * 4);
+            p->winp.push_back(d);
+            p->win_img[{in_ws, src_off}] = d.dst_off;
+            if (vecs > p->winp_max) p->winp_max = vecs;
+        };
+        for (int i = 1; i < L; ++i) add_win(0, p->down[i].woff, p->down[i].KW, p->down[i].Cin, p->down[i].Cout);
+        add_win(0, p->bott.woff, p->bott.KW, p->bott.Cin, p->bott.Cout);
+        for (int j = 0; j < L; ++j) add_win(0, p->up[j].woff, p->up[j].KW, p->up[j].Cin, p->up[j].Cout);
+        p->nwinp_fwd = (int)p->winp.size();
+        // stride-1 input gradients: wt_full is [K][Cout][Cin], i.e. a conv from Cout to Cin channels
+        for (int i = 1; i < L; ++i) add_win(1, p->down[i].wt_full, p->down[i].KW, p->down[i].Cout, p->down[i].Cin);
+        add_win(1, p->bott.wt_full, p->bott.KW, p->bott.Cout, p->bott.Cin);
+        for (int j = 0; j < L; ++j) add_win(1, p->up[j].wt_full, p->up[j].KW, p->up[j].Cout, p->up[j].Cin);
+    }
+
     // ---- bf16 mode: packed weight images (every conv with >= 8 input channels; the audio-input conv and the
     // output head stay exact fp32) ----
     p->bf16 = cfg->compute_dtype == 1;
@@ -427,6 +456,11 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
             (void)hipGetLastError();
         }
     }
+    if (!p->winp.empty()) {
+        hipError_t e = hipMalloc((void**)&p->dev_winp, p->winp.size() * sizeof(WinPackDesc));
+        if (e == hipSuccess) e = hipMemcpy(p->dev_winp, p->winp.data(), p->winp.size() * sizeof(WinPackDesc), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { p->dev_winp = nullptr; p->win_img.clear(); (void)hipGetLastError(); }
+    }
     if (!p->pack.empty()) {
         hipError_t e = hipMalloc((void**)&p->dev_pack, p->pack.size() * sizeof(PackDesc));
         if (e == hipSuccess) e = hipMemcpy(p->dev_pack, p->pack.data(), p->pack.size() * sizeof(PackDesc), hipMemcpyHostToDevice);
@@ -440,6 +474,7 @@ extern "C" void wun_plan_destroy(wun_plan* p) {
     if (!p) return;
     if (p->dev_wt) (void)hipFree(p->dev_wt);
     if (p->dev_pack) (void)hipFree(p->dev_pack);
+    if (p->dev_winp) (void)hipFree(p->dev_winp);
     for (auto e : p->events) (void)hipEventDestroy(e);
     if (p->tev0) { (void)hipEventDestroy(p->tev0); (void)hipEventDestroy(p->tev1); }
     if (p->wt_ev) (void)hipEventDestroy(p->wt_ev);
@@ -669,6 +704,11 @@ static hipError_t conv_dispatch(const wun_plan* p, ConvArgs a, float* part, long
             return launch_conv_bf16(a, s);
         }
     }
+    if (!p->bf16 && !p->win_img.empty() && a.W != nullptr) {
+        const bool in_ws = a.W >= p->cur_ws && a.W < p->cur_ws + p->ws;
+        auto it = p->win_img.find({in_ws ? 1 : 0, (long long)(a.W - (in_ws ? p->cur_ws : p->cur_params))});
+        if (it != p->win_img.end()) a.Wwin = p->cur_ws + it->second;
+    }
     if (p->tune_mode == 1) {
         if (vec.size() <= idx) vec.resize(idx + 1, ConvChoice{-1, 0});
         static ConvChoice cands[640];
@@ -736,6 +776,8 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
         if (!p->dev_pack) return fail(WUN_ERR_HIP, "plan was created without a usable HIP device");
         HIP_TRY(launch_pack_bf16(params, ws, p->dev_pack, p->npack_fwd, p->pack_max, s));
     }
+    if (!p->bf16 && p->dev_winp && p->nwinp_fwd > 0)
+        HIP_TRY(launch_pack_win(params, ws, p->dev_winp, p->nwinp_fwd, p->winp_max, s));
     p->wt_ready = false;
     if (training && !p->wt.empty() && p->dev_wt && s2 != s) {
         // the backward pass will need tap-flipped / transposed copies of every kernel: make them now,
@@ -745,6 +787,8 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
         HIP_TRY(launch_make_wt(params, ws, p->dev_wt, (int)p->wt.size(), p->wt_max, s2));
         if (p->bf16)
             HIP_TRY(launch_pack_bf16(params, ws, p->dev_pack + p->npack_fwd, (int)p->pack.size() - p->npack_fwd, p->pack_max, s2));
+        if (!p->bf16 && p->dev_winp && (int)p->winp.size() > p->nwinp_fwd)
+            HIP_TRY(launch_pack_win(params, ws, p->dev_winp + p->nwinp_fwd, (int)p->winp.size() - p->nwinp_fwd, p->winp_max, s2));
         HIP_TRY(hipEventRecord(p->wt_ev, s2));
         p->wt_ready = true;
         side_used = true;
@@ -1241,6 +1285,8 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
         HIP_TRY(launch_make_wt(params, ws, p->dev_wt, (int)p->wt.size(), p->wt_max, s));
         if (p->bf16)
             HIP_TRY(launch_pack_bf16(params, ws, p->dev_pack + p->npack_fwd, (int)p->pack.size() - p->npack_fwd, p->pack_max, s));
+        if (!p->bf16 && p->dev_winp && (int)p->winp.size() > p->nwinp_fwd)
+            HIP_TRY(launch_pack_win(params, ws, p->dev_winp + p->nwinp_fwd, (int)p->winp.size() - p->nwinp_fwd, p->winp_max, s));
     }
     p->cur_params = params; p->cur_ws = ws;
 
@@ -1581,8 +1627,27 @@ static float* op_scratch() {
     return buf;
 }
 
+// window-layout copy of a single operator's weights (the plan makes these once per step; here per call)
+static const float* op_win_weights(const ConvArgs& a, hipStream_t s) {
+    static float* buf = nullptr;
+    static WinPackDesc* dd = nullptr;
+    const long long kOpWinFloats = 16ll << 20;
+    const int Ctot = a.C0 + a.C1;
+    const long long vecs = (long long)Ctot * ((a.KW + 3) / 4) * a.N;
+    if (!(a.KW == 15 || a.KW == 5) || a.W == nullptr || vecs * 4 > kOpWinFloats) return nullptr;
+    if (!buf && hipMalloc((void**)&buf, kOpWinFloats * sizeof(float)) != hipSuccess) { buf = nullptr; (void)hipGetLastError(); return nullptr; }
+    if (!dd && hipMalloc((void**)&dd, sizeof(WinPackDesc)) != hipSuccess) { dd = nullptr; (void)hipGetLastError(); return nullptr; }
+    WinPackDesc d;
+    d.src_off = 0; d.dst_off = 0; d.K = a.KW; d.C = Ctot; d.N = a.N; d.src_in_ws = 0;
+    if (hipMemcpyAsync(dd, &d, sizeof(d), hipMemcpyHostToDevice, s) != hipSuccess) return nullptr;
+    if (hipStreamSynchronize(s) != hipSuccess) return nullptr;                 // (d lives on this stack frame)
+    if (launch_pack_win(a.W, buf, dd, 1, vecs, s) != hipSuccess) return nullptr;
+    return buf;
+}
+
 static hipError_t op_launch_conv(ConvArgs a, hipStream_t s) {
     if (g_op_variant >= 0) { a.force_variant = g_op_variant + 1; a.force_ksplit = (a.flags & F_PHASE2) ? 0 : g_op_ksplit; }
+    if (g_op_variant >= WUN_FIRST_WIN_VARIANT) a.Wwin = op_win_weights(a, s);
     return launch_conv(a, op_scratch(), kOpScratchFloats, s);
 }
 
