@@ -61,7 +61,7 @@ def _t_out(T, K, stride, same):
 # (B, Cin, Cout, K, T, same)  -- chosen so that, between them, every tile variant is a legal choice:
 # N = 48 admits 32/48/64/80-column tiles, N = 96 admits 96/128-column tiles, T >= 400 admits 384-row
 # tiles, the 1-/2-channel cases admit the 4-channel-chunk audio-input tiles, the B = 16 short cases
-# the batch-folded tiles.
+# the batch-folded tiles; the last three the register-window tiles of wun_conv_win.hip.
 SWEEP_CASES = [
     (2, 24, 48, 15, 800, False),
     (2, 40, 96, 5, 420, True),
@@ -72,6 +72,10 @@ SWEEP_CASES = [
     (16, 48, 96, 15, 95, False),
     (6, 72, 48, 5, 77, True),
     (16, 24, 64, 15, 151, False),
+    # the register-window tiles (variants >= 42) want 16-byte aligned output rows: lengths whose outputs are multiples of 4
+    (2, 24, 48, 15, 814, False),
+    (2, 48, 96, 15, 814, False),
+    (2, 48, 80, 5, 404, False),
 ]
 
 

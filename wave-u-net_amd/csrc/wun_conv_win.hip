@@ -45,8 +45,8 @@ __device__ __forceinline__ int cw_xcd_block(int bid, int grid) {
     return xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
 }
 
-#define WUN_CW_XIT 5      // 16-byte input slots per thread and chunk (4 rows x pitch / 4 over 256 threads)
-#define WUN_CW_WIT 8      // 16-byte weight slots per thread and chunk (4 channels x tap groups x NT over 256 threads)
+#define WUN_CW_XIT 5      // DMA instructions per input row (row pitch <= 768 floats)
+#define WUN_CW_WIT 6      // DMA instructions per weight channel (tap groups x NT <= 384 slots)
 
 #ifdef WUN_CW_TRACE
 // diagnostic builds only (tools/cw_trace.py): per workgroup and wave {100 MHz clock at entry / exit} + per chunk
@@ -61,13 +61,16 @@ struct ConvWinParams {
     int WT, WN;          // waves along time / along output channels (WT * WN == 4)
     int TT, NT;          // workgroup tile: positions x output channels
     int nTT, nNT;
-    int XP;              // LDS row pitch of the input rows (floats, multiple of 64: conflict-free 16-byte window reads)
+    int XP;              // LDS row pitch of the input rows (floats, multiple of 256: whole 1 KiB DMA blocks, conflict-free reads)
     int XGL;             // live 16-byte granules per input row
+    int WR;              // 16-byte slots per weight channel in LDS (tap groups x NT, padded to whole DMA blocks)
     int woff;            // float offset of the weight region in a buffer
-    int bufFloats;       // floats per LDS buffer {4 input rows, weights [4][KG][NT][4]}
+    int bufFloats;       // floats per LDS buffer {4 CQ input rows, weights [4 CQ][KG][NT][4]}
+    unsigned nt_inv;     // ceil(65536 / NT): slot -> (tap group, column) without a division
 };
 
-template <int K, int S, int MB, int NW>
+// CQ = channel quads (MFMA k-steps worth of channels) per chunk, i.e. per barrier
+template <int K, int S, int MB, int NW, int CQ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MB * NW <= 3 ? 3 : 2)))
 void conv_win_kernel(ConvArgs a, ConvWinParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -86,52 +89,34 @@ void conv_win_kernel(ConvArgs a, ConvWinParams p) {
     const int q0 = tt * p.TT, n0 = nt * p.NT;
     const int wq0 = q0 + wt * MB * 64, wn0 = n0 + wn * NW * 16;
     const int Ctot = a.C0 + a.C1;
-    const int nchunks = Ctot >> 2;
+    const int nchunks = Ctot / (4 * CQ);
     const int t0 = S * q0 - a.shift;                    // time index of the first staged input sample
 
-    // ---- chunk-invariant DMA state: byte offsets of this thread's slots from the chunk's uniform base pointers ----
-    const int XG = p.XP >> 2;
+    // ---- staging map, no per-thread division: wave w stages input rows / weight channels w, w + 4, ...; lane l of DMA
+    // instruction i covers slot 64 i + l of its row / channel.  Chunk-invariant byte offsets from uniform base pointers:
+    const int XG = p.XP >> 2;                           // slots per input row (multiple of 64)
+    const int nxi = XG >> 6, nwi = p.WR >> 6;           // DMA instructions per row / per channel
     unsigned xb[WUN_CW_XIT], wb[WUN_CW_WIT];
-    const float inv_xg = 1.0f / (float)XG;
-    const int wrow4 = KG * p.NT;                        // 16-byte slots per channel in the LDS weight region
-    const float inv_wr = 1.0f / (float)wrow4, inv_nt = 1.0f / (float)p.NT;
-    auto xslot = [&](int f, int& row, int& g) __attribute__((always_inline)) {
-        row = (int)(((float)f + 0.5f) * inv_xg);
-        g = f - row * XG;
-        if (g < 0) { --row; g += XG; } else if (g >= XG) { ++row; g -= XG; }
-    };
 #pragma unroll
     for (int i = 0; i < WUN_CW_XIT; ++i) {
-        int row, g;
-        xslot(tid + i * 256, row, g);
-        row = row < 4 ? row : 3;
-        // (pitch0 / pitch1 differ per source: the offset is in units of "rows", resolved per chunk below)
-        xb[i] = ((unsigned)row << 24) | (unsigned)(16 * (g < p.XGL ? g : p.XGL - 1));
+        const int g = 64 * i + lane;
+        xb[i] = 16u * (unsigned)(g < p.XGL ? g : p.XGL - 1);
     }
 #pragma unroll
     for (int i = 0; i < WUN_CW_WIT; ++i) {
-        const int f = tid + i * 256;
-        int cl = (int)(((float)f + 0.5f) * inv_wr);
-        int r = f - cl * wrow4;
-        if (r < 0) { --cl; r += wrow4; } else if (r >= wrow4) { ++cl; r -= wrow4; }
-        int kg = (int)(((float)r + 0.5f) * inv_nt);
-        int n = r - kg * p.NT;
-        if (n < 0) { --kg; n += p.NT; } else if (n >= p.NT) { ++kg; n -= p.NT; }
-        cl = cl < 4 ? cl : 3;
-        int ng = n0 + n;
+        int sl = 64 * i + lane;
+        sl = sl < KG * p.NT ? sl : KG * p.NT - 1;        // pad slots re-fetch the last one
+        const int kg = (int)(((unsigned)sl * p.nt_inv) >> 16);
+        int ng = n0 + sl - kg * p.NT;
         ng = ng < a.N ? ng : a.N - 1;                    // padded columns: any valid weights (results never stored)
-        wb[i] = 16u * (unsigned)((cl * KG + kg) * a.N + ng);       // window layout [c][kg][n][4]
+        wb[i] = 16u * (unsigned)(kg * a.N + ng);         // window layout [c][kg][n][4]
     }
-    const int nxpad = (4 * XG + 63) & ~63, nwpad = (4 * wrow4 + 63) & ~63;
-    const int nxi = (int)cw_sgpr((unsigned)((nxpad - wave * 64 + 255) / 256));
-    const int nwi = (int)cw_sgpr((unsigned)((nwpad - wave * 64 + 255) / 256));
     const unsigned lds_base = (unsigned)(unsigned long long)(lds_void_t*)lds;
-    const unsigned m0w = cw_sgpr(lds_base + 16u * (unsigned)(wave * 64));
     const bool edge = t0 < 0 || t0 + 4 * p.XGL > a.Tin;           // tile touches the zero padding (or the row end)
 
-    // input rows of chunk `ch` (channels 4 ch .. 4 ch + 3, one source)
+    // source rows of chunk `ch` (channels 4 CQ ch .., one source)
     auto chunk_src = [&](int ch, int& pitch, int& off) __attribute__((always_inline)) -> const float* {
-        const int c0 = 4 * ch;
+        const int c0 = 4 * CQ * ch;
         if (c0 < a.C0) { pitch = a.pitch0; off = a.off0; return a.src0 + (long long)b * a.bs0 + (long long)c0 * a.pitch0; }
         pitch = a.pitch1; off = a.off1;
         return a.src1 + (long long)b * a.bs1 + (long long)(c0 - a.C0) * a.pitch1;
@@ -139,61 +124,60 @@ void conv_win_kernel(ConvArgs a, ConvWinParams p) {
     auto dma_chunk = [&](int ch, int bo) __attribute__((always_inline)) {
         int pitch, off;
         const float* rows = chunk_src(ch, pitch, off);
-        if (!edge) {
-            const float* xbs = cw_sgpr_ptr(rows + off + t0);
-            const unsigned m0x = cw_sgpr(m0w + 4u * (unsigned)bo);
-            const unsigned pb = 4u * (unsigned)pitch;
+        const unsigned m0b = cw_sgpr(lds_base + 4u * (unsigned)bo);
 #pragma unroll
-            for (int i = 0; i < WUN_CW_XIT; ++i)
-                if (i < nxi) cw_dma16(m0x + 4096u * (unsigned)i, (xb[i] >> 24) * pb + (xb[i] & 0xFFFFFFu), xbs);
-        } else {
-            // clamp every 16 bytes into its source row; zero_fix() repairs the samples outside [0, Tin)
+        for (int r = 0; r < CQ; ++r) {
+            const int row = wave + 4 * r;
+            const unsigned m0x = m0b + 16u * (unsigned)(row * XG);
+            if (!edge) {
+                const float* xbs = cw_sgpr_ptr(rows + (long long)row * pitch + off + t0);
 #pragma unroll
-            for (int i = 0; i < WUN_CW_XIT; ++i) {
-                if (i * 256 + wave * 64 < 4 * XG) {
-                    int row, g, fo = tid + i * 256;
-                    asm volatile("" : "+v"(fo));
-                    xslot(fo, row, g);
-                    if (row < 4 && g < p.XGL) {
-                        int er = 4 * g + off + t0;
+                for (int i = 0; i < WUN_CW_XIT; ++i)
+                    if (i < nxi) cw_dma16(m0x + 1024u * (unsigned)i, xb[i], xbs);
+            } else {
+                // clamp every 16 bytes into its source row; zero_fix() repairs the samples outside [0, Tin)
+#pragma unroll
+                for (int i = 0; i < WUN_CW_XIT; ++i)
+                    if (i < nxi) {
+                        int er = (int)(xb[i] >> 2) + off + t0;
                         er = er < 0 ? 0 : (er > pitch - 4 ? pitch - 4 : er);
                         __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(rows + (long long)row * pitch + er),
-                                                         (lds_void_t*)(lds + bo + (i * 256 + wave * 64) * 4), 16, 0, 0);
+                                                         (lds_void_t*)(lds + bo + 4 * (row * XG + 64 * i)), 16, 0, 0);
                     }
-                }
             }
-        }
-        const float* wbs = cw_sgpr_ptr(a.Wwin + (long long)ch * 4 * KG * a.N * 4);
-        const unsigned m0v = cw_sgpr(m0w + 4u * (unsigned)(bo + p.woff));
+            const float* wbs = cw_sgpr_ptr(a.Wwin + ((long long)(4 * CQ * ch + row) * KG) * a.N * 4);
+            const unsigned m0v = m0b + 4u * (unsigned)p.woff + 16u * (unsigned)(row * p.WR);
 #pragma unroll
-        for (int i = 0; i < WUN_CW_WIT; ++i)
-            if (i < nwi) cw_dma16(m0v + 4096u * (unsigned)i, wb[i], wbs);
+            for (int i = 0; i < WUN_CW_WIT; ++i)
+                if (i < nwi) cw_dma16(m0v + 1024u * (unsigned)i, wb[i], wbs);
+        }
     };
     auto zero_fix = [&](int ch, int bo) __attribute__((always_inline)) {
         int pitch, off;
         (void)chunk_src(ch, pitch, off);
 #pragma unroll
-        for (int i = 0; i < WUN_CW_XIT; ++i) {
-            int f = tid + i * 256;
-            asm volatile("" : "+v"(f));
-            int row, g;
-            xslot(f, row, g);
-            if (f < 4 * XG && row < 4 && g < p.XGL) {
-                const int er0 = off + t0 + 4 * g;
-                const int erc = er0 < 0 ? 0 : (er0 > pitch - 4 ? pitch - 4 : er0);
-                f32x4 v = *reinterpret_cast<f32x4*>(lds + bo + 4 * f);
-                f32x4 w;
+        for (int r = 0; r < CQ; ++r)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int t = t0 + 4 * g + k;
-                    const int j = er0 + k - erc;
-                    float x = 0.f;
-                    if (t >= 0 && t < a.Tin && j >= 0 && j < 4) x = j == 0 ? v[0] : j == 1 ? v[1] : j == 2 ? v[2] : v[3];
-                    w[k] = x;
+            for (int i = 0; i < WUN_CW_XIT; ++i) {
+                int g = 64 * i + lane;
+                asm volatile("" : "+v"(g));
+                if (i < nxi && g < p.XGL) {
+                    float* q = lds + bo + 4 * ((wave + 4 * r) * XG + g);
+                    const int er0 = off + t0 + 4 * g;
+                    const int erc = er0 < 0 ? 0 : (er0 > pitch - 4 ? pitch - 4 : er0);
+                    f32x4 v = *reinterpret_cast<f32x4*>(q);
+                    f32x4 w;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int t = t0 + 4 * g + k;
+                        const int j = er0 + k - erc;
+                        float x = 0.f;
+                        if (t >= 0 && t < a.Tin && j >= 0 && j < 4) x = j == 0 ? v[0] : j == 1 ? v[1] : j == 2 ? v[2] : v[3];
+                        w[k] = x;
+                    }
+                    *reinterpret_cast<f32x4*>(q) = w;
                 }
-                *reinterpret_cast<f32x4*>(lds + bo + 4 * f) = w;
             }
-        }
     };
 
     f32x4 acc[MB][4][NW];
@@ -204,42 +188,46 @@ void conv_win_kernel(ConvArgs a, ConvWinParams p) {
 #pragma unroll
             for (int n = 0; n < NW; ++n) acc[mb][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // lane's LDS read positions: input row lg, window at float S (wave offset + 4 li); weights of channel lg, column li
+    // lane's LDS read positions: input row lg (+ 4 per quad), window at float S (wave offset + 4 li); weights of channel
+    // lg, column li
     const int xrd = lg * p.XP + S * (wt * MB * 64 + 4 * li);
-    const int wrd = p.woff + 4 * (lg * wrow4 + wn * NW * 16 + li);
+    const int wrd = p.woff + 4 * (lg * p.WR + wn * NW * 16 + li);
 
     auto mfma_chunk = [&](int bo, auto&& mid) __attribute__((always_inline)) {
-        const float* xp = lds + bo + xrd;
-        const float* wp = lds + bo + wrd;
-        f32x4 win[MB][NWIN];
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
+        for (int qd = 0; qd < CQ; ++qd) {
+            const float* xp = lds + bo + xrd + 4 * qd * p.XP;
+            const float* wp = lds + bo + wrd + 16 * qd * p.WR;
+            f32x4 win[MB][NWIN];
 #pragma unroll
-            for (int j = 0; j < NWIN; ++j) win[mb][j] = *reinterpret_cast<const f32x4*>(xp + S * 64 * mb + 4 * j);
-        f32x4 bv[2][NW];
+            for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int n = 0; n < NW; ++n) bv[0][n] = *reinterpret_cast<const f32x4*>(wp + 64 * n);
+                for (int j = 0; j < NWIN; ++j) win[mb][j] = *reinterpret_cast<const f32x4*>(xp + S * 64 * mb + 4 * j);
+            f32x4 bv[2][NW];
 #pragma unroll
-        for (int kg = 0; kg < KG; ++kg) {
-            if (kg + 1 < KG) {
+            for (int n = 0; n < NW; ++n) bv[0][n] = *reinterpret_cast<const f32x4*>(wp + 64 * n);
 #pragma unroll
-                for (int n = 0; n < NW; ++n) bv[(kg + 1) & 1][n] = *reinterpret_cast<const f32x4*>(wp + 4 * (kg + 1) * p.NT + 64 * n);
-            }
+            for (int kg = 0; kg < KG; ++kg) {
+                if (kg + 1 < KG) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = 4 * kg + j;
-                if (k >= K) continue;
-                if (kg == 0 && j == 1) mid();            // the next chunk's DMA: issued from inside the MFMA stream
+                    for (int n = 0; n < NW; ++n) bv[(kg + 1) & 1][n] = *reinterpret_cast<const f32x4*>(wp + 4 * (kg + 1) * p.NT + 64 * n);
+                }
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
+                for (int j = 0; j < 4; ++j) {
+                    const int k = 4 * kg + j;
+                    if (k >= K) continue;
+                    if (qd == 0 && kg == 0 && j == 1) mid();     // the next chunk's DMA: issued from inside the MFMA stream
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        const int e = S * m + k;
-                        const float av = win[mb][e >> 2][e & 3];
+                    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                        for (int n = 0; n < NW; ++n)
-                            acc[mb][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[kg & 1][n][j], acc[mb][m][n], 0, 0, 0);
-                    }
+                        for (int m = 0; m < 4; ++m) {
+                            const int e = S * m + k;
+                            const float av = win[mb][e >> 2][e & 3];
+#pragma unroll
+                            for (int n = 0; n < NW; ++n)
+                                acc[mb][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[kg & 1][n][j], acc[mb][m][n], 0, 0, 0);
+                        }
+                }
             }
         }
     };
@@ -272,62 +260,73 @@ void conv_win_kernel(ConvArgs a, ConvWinParams p) {
     if (tr_on) trp[4] = __builtin_readcyclecounter();
 #endif
 
-    // ---- epilogue: lane (li, lg) holds, for column wn0 + 16 n + li, the positions wq0 + 64 mb + 16 lg + 4 r + {0..3} ----
+    // ---- epilogue: lane (li, lg) holds, for column wn0 + 16 n + li, the positions wq0 + 64 mb + 16 lg + 4 r + {0..3}.
+    // FULL = the whole workgroup tile lies inside [0, Tout) x [0, N): no bounds tests (all but the last tiles) ----
     const bool lrelu = (a.flags & F_LRELU) != 0;
     const bool accum = (a.flags & F_ACCUM) != 0;
+    auto epilogue = [&](auto full_c) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
-    for (int n = 0; n < NW; ++n) {
-        const int ncol = wn0 + n * 16 + li;
-        if (ncol >= a.N) continue;
-        const float bvv = (a.bias != nullptr) ? a.bias[ncol] : 0.f;
-        float* dst; const float* msk; long long rowbase; int ooff;
-        if (ncol < a.N0) {
-            rowbase = (long long)b * a.obs0 + (long long)ncol * a.opitch0 + a.ooff0;
-            dst = a.dst0; msk = a.msk0; ooff = a.ooff0;
-        } else {
-            rowbase = (long long)b * a.obs1 + (long long)(ncol - a.N0) * a.opitch1 + a.ooff1;
-            dst = a.dst1; msk = a.msk1; ooff = a.ooff1;
-        }
+        for (int n = 0; n < NW; ++n) {
+            const int ncol = wn0 + n * 16 + li;
+            if (!FULL && ncol >= a.N) continue;
+            const float bvv = (a.bias != nullptr) ? a.bias[ncol] : 0.f;
+            float* dst; const float* msk; int ooff;
+            if (ncol < a.N0) {
+                dst = a.dst0 + (long long)b * a.obs0 + (long long)ncol * a.opitch0 + a.ooff0;
+                msk = a.msk0 != nullptr ? a.msk0 + (long long)b * a.obs0 + (long long)ncol * a.opitch0 + a.ooff0 : nullptr;
+                ooff = a.ooff0;
+            } else {
+                dst = a.dst1 + (long long)b * a.obs1 + (long long)(ncol - a.N0) * a.opitch1 + a.ooff1;
+                msk = a.msk1 != nullptr ? a.msk1 + (long long)b * a.obs1 + (long long)(ncol - a.N0) * a.opitch1 + a.ooff1 : nullptr;
+                ooff = a.ooff1;
+            }
+            const int qb = wq0 + 16 * lg;
+            dst += qb;
+            if (msk != nullptr) msk += qb;
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
+            for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int q = wq0 + 64 * mb + 16 * lg + 4 * r;
-                if (q >= a.Tout) continue;
-                f32x4 v = {acc[mb][0][n][r], acc[mb][1][n][r], acc[mb][2][n][r], acc[mb][3][n][r]};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] += bvv;
-                    if (lrelu) v[e] = fmaxf(0.2f * v[e], v[e]);
-                }
-                const long long idx = rowbase + q;
-                if (q + 3 < a.Tout) {
-                    if (msk != nullptr) {
-                        const f32x4 mk = *reinterpret_cast<const f32x4*>(&msk[idx]);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] *= (mk[e] > 0.f) ? 1.f : 0.2f;
-                    }
-                    const int pos0 = ooff + q;
-                    if (accum && (conv_acc_at(a, pos0) || conv_acc_at(a, pos0 + 3))) {
-                        const f32x4 old = *reinterpret_cast<const f32x4*>(&dst[idx]);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (conv_acc_at(a, pos0 + e)) v[e] += old[e];
-                    }
-                    *reinterpret_cast<f32x4*>(&dst[idx]) = v;
-                } else {
+                for (int r = 0; r < 4; ++r) {
+                    const int dq = 64 * mb + 4 * r;                  // compile-time offset from qb
+                    const int q = qb + dq;
+                    if (!FULL && q >= a.Tout) continue;
+                    f32x4 v = {acc[mb][0][n][r], acc[mb][1][n][r], acc[mb][2][n][r], acc[mb][3][n][r]};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if (q + e < a.Tout) {
-                            float x = v[e];
-                            if (msk != nullptr) x *= (msk[idx + e] > 0.f) ? 1.f : 0.2f;
-                            if (accum && conv_acc_at(a, ooff + q + e)) x += dst[idx + e];
-                            dst[idx + e] = x;
+                        v[e] += bvv;
+                        if (lrelu) v[e] = fmaxf(0.2f * v[e], v[e]);
+                    }
+                    if (FULL || q + 3 < a.Tout) {
+                        if (msk != nullptr) {
+                            const f32x4 mk = *reinterpret_cast<const f32x4*>(msk + dq);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] *= (mk[e] > 0.f) ? 1.f : 0.2f;
+                        }
+                        const int pos0 = ooff + q;
+                        if (accum && (conv_acc_at(a, pos0) || conv_acc_at(a, pos0 + 3))) {
+                            const f32x4 old = *reinterpret_cast<const f32x4*>(dst + dq);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (conv_acc_at(a, pos0 + e)) v[e] += old[e];
+                        }
+                        *reinterpret_cast<f32x4*>(dst + dq) = v;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (q + e < a.Tout) {
+                                float x = v[e];
+                                if (msk != nullptr) x *= (msk[dq + e] > 0.f) ? 1.f : 0.2f;
+                                if (accum && conv_acc_at(a, ooff + q + e)) x += dst[dq + e];
+                                dst[dq + e] = x;
+                            }
                         }
                     }
                 }
-            }
-    }
+        }
+    };
+    if (q0 + p.TT <= a.Tout && n0 + p.NT <= a.N) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
 #ifdef WUN_CW_TRACE
     if (tr_on) { trp[5] = __builtin_readcyclecounter(); trp[2] = wall_clock64(); }
 #endif
@@ -368,18 +367,22 @@ hipError_t launch_pack_win(const float* params, float* ws, const WinPackDesc* de
 }
 
 // ---- tile menu: (MB, NW, WT, WN): positions per workgroup = WT * MB * 64, output channels = WN * NW * 16 ----
-struct ConvWinVariant { int MB, NW, WT, WN; };
+struct ConvWinVariant { int MB, NW, WT, WN, CQ; };
 static const ConvWinVariant kWinVariants[] = {
-    {1, 3, 4, 1},      // 256 x 48
-    {1, 2, 4, 1},      // 256 x 32
-    {1, 4, 4, 1},      // 256 x 64
-    {1, 5, 4, 1},      // 256 x 80
-    {2, 3, 4, 1},      // 512 x 48
-    {1, 3, 2, 2},      // 128 x 96
-    {2, 3, 2, 2},      // 256 x 96
-    {1, 4, 2, 2},      // 128 x 128
-    {2, 2, 4, 1},      // 512 x 32
-    {1, 3, 1, 4},      //  64 x 192
+    {1, 3, 4, 1, 1},      // 256 x 48, 4 channels per barrier
+    {1, 2, 4, 1, 1},      // 256 x 32
+    {1, 4, 4, 1, 1},      // 256 x 64
+    {1, 5, 4, 1, 1},      // 256 x 80
+    {2, 3, 4, 1, 1},      // 512 x 48
+    {1, 3, 2, 2, 1},      // 128 x 96
+    {2, 3, 2, 2, 1},      // 256 x 96
+    {2, 2, 4, 1, 1},      // 512 x 32
+    {1, 3, 4, 1, 2},      // 256 x 48, 8 channels per barrier
+    {2, 3, 4, 1, 2},      // 512 x 48
+    {1, 2, 4, 1, 2},      // 256 x 32
+    {2, 2, 4, 1, 2},      // 512 x 32
+    {1, 3, 2, 2, 2},      // 128 x 96
+    {2, 3, 2, 2, 2},      // 256 x 96
 };
 int conv_win_num_variants() { return (int)(sizeof(kWinVariants) / sizeof(kWinVariants[0])); }
 
@@ -391,16 +394,19 @@ static bool conv_win_geom(const ConvArgs& a, int wv, ConvWinParams& p, size_t& l
     const int S = a.loader == LOADER_DEINT ? 2 : 1;
     const int K = a.KW, KG = (K + 3) / 4;
     const int NWIN = (3 * S + K + 3) / 4;
+    const int CQ = v.CQ;
     p.WT = v.WT; p.WN = v.WN;
     p.TT = v.WT * v.MB * 64; p.NT = v.WN * v.NW * 16;
     p.nTT = (a.Tout + p.TT - 1) / p.TT; p.nNT = (a.N + p.NT - 1) / p.NT;
     const int need = std::max(S * (p.TT - 1) + K, S * (p.TT - 4) + 4 * NWIN);
     p.XGL = (need + 3) / 4;
-    p.XP = ((4 * p.XGL + 63) / 64) * 64;
-    p.woff = 4 * ((4 * (p.XP / 4) + 63) & ~63);
-    p.bufFloats = p.woff + 4 * ((4 * KG * p.NT + 63) & ~63);
+    p.XP = ((4 * p.XGL + 255) / 256) * 256;
+    p.WR = (KG * p.NT + 63) & ~63;
+    p.woff = 4 * CQ * p.XP;
+    p.bufFloats = p.woff + 4 * (4 * CQ * p.WR);
+    p.nt_inv = (65536u + (unsigned)p.NT - 1) / (unsigned)p.NT;
     lds = sizeof(float) * 2 * (size_t)p.bufFloats;
-    if (4 * (p.XP / 4) > WUN_CW_XIT * 256 || 4 * KG * p.NT > WUN_CW_WIT * 256) return false;
+    if ((p.XP >> 8) > WUN_CW_XIT || (p.WR >> 6) > WUN_CW_WIT) return false;
     return lds <= 96 * 1024;
 }
 
@@ -410,7 +416,9 @@ bool conv_win_ok(const ConvArgs& a, int wv) {
     if (off || a.Wwin == nullptr) return false;
     if (!(a.KW == 15 || a.KW == 5)) return false;
     const int Ctot = a.C0 + a.C1;
-    if (Ctot < 8 || (Ctot & 3) != 0 || (a.C0 & 3) != 0 || (a.N & 3) != 0 || a.N < 16) return false;
+    if (wv < 0 || wv >= conv_win_num_variants()) return false;
+    const int cq4 = 4 * kWinVariants[wv].CQ;
+    if (Ctot < 8 || (Ctot % cq4) != 0 || (a.C0 % cq4) != 0 || (a.N & 3) != 0 || a.N < 16) return false;
     if (a.flags & F_PHASE2) return false;
     if (a.loader == LOADER_DEINT && a.KW != 15) return false;
     if (a.ostride != 1 || a.dec != nullptr || a.ups_y != nullptr || a.ubw_dz != nullptr) return false;
@@ -420,7 +428,6 @@ bool conv_win_ok(const ConvArgs& a, int wv) {
     if (a.msk0 != nullptr) vec = vec && cw_aligned16(a.msk0);
     if (a.msk1 != nullptr) vec = vec && cw_aligned16(a.msk1);
     if (!vec || !cw_aligned16(a.Wwin)) return false;
-    if ((long long)4 * std::max(a.pitch0, a.pitch1) * 4 >= (1ll << 24)) return false;      // row offsets packed in 24 bits
     if ((long long)4 * ((a.KW + 3) / 4) * a.N * 16 >= (1ll << 31)) return false;
     ConvWinParams p;
     size_t lds;
@@ -453,9 +460,9 @@ int conv_win_pick(const ConvArgs& a) {
     return best;
 }
 
-template <int K, int S, int MB, int NW>
+template <int K, int S, int MB, int NW, int CQ>
 static hipError_t conv_win_launch_t(const ConvArgs& a, const ConvWinParams& p, size_t lds, hipStream_t s) {
-    auto kern = conv_win_kernel<K, S, MB, NW>;
+    auto kern = conv_win_kernel<K, S, MB, NW, CQ>;
     static size_t lds_allowed = 64 * 1024;
     if (lds > lds_allowed) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -465,7 +472,7 @@ static hipError_t conv_win_launch_t(const ConvArgs& a, const ConvWinParams& p, s
     const long long grid = (long long)p.nTT * p.nNT * a.B;
     if (grid <= 0) return hipSuccess;
     char nm[64];
-    snprintf(nm, sizeof(nm), "conv_win_kernel<%d, %d, %d, %d>", K, S, MB, NW);
+    snprintf(nm, sizeof(nm), "conv_win_kernel<%d, %d, %d, %d, %d>", K, S, MB, NW, CQ);
     char tag[160];
     snprintf(tag, sizeof(tag), "C=%d N=%d T=%d K=%d ld=%d B=%d tile=%dx%d acc=%d grid=%lld", a.C0 + a.C1, a.N, a.Tout, a.KW,
              a.loader, a.B, p.TT, p.NT, (a.flags & F_ACCUM) ? 1 : 0, grid);
@@ -484,10 +491,11 @@ hipError_t launch_conv_win(const ConvArgs& a_in, int wv, hipStream_t s) {
     conv_win_geom(a, wv, p, lds);
     const ConvWinVariant& v = kWinVariants[wv];
     const int S = a.loader == LOADER_DEINT ? 2 : 1;
-#define WUN_CWL(k, ss, mb, nw) if (a.KW == k && S == ss && v.MB == mb && v.NW == nw) return conv_win_launch_t<k, ss, mb, nw>(a, p, lds, s);
-    WUN_CWL(15, 1, 1, 2) WUN_CWL(15, 1, 1, 3) WUN_CWL(15, 1, 1, 4) WUN_CWL(15, 1, 1, 5) WUN_CWL(15, 1, 2, 2) WUN_CWL(15, 1, 2, 3)
-    WUN_CWL(15, 2, 1, 2) WUN_CWL(15, 2, 1, 3) WUN_CWL(15, 2, 1, 4) WUN_CWL(15, 2, 1, 5) WUN_CWL(15, 2, 2, 2) WUN_CWL(15, 2, 2, 3)
-    WUN_CWL(5, 1, 1, 2) WUN_CWL(5, 1, 1, 3) WUN_CWL(5, 1, 1, 4) WUN_CWL(5, 1, 1, 5) WUN_CWL(5, 1, 2, 2) WUN_CWL(5, 1, 2, 3)
+#define WUN_CWL(k, ss, mb, nw, cq) if (a.KW == k && S == ss && v.MB == mb && v.NW == nw && v.CQ == cq) return conv_win_launch_t<k, ss, mb, nw, cq>(a, p, lds, s);
+#define WUN_CWL_ALL(k, ss) WUN_CWL(k, ss, 1, 2, 1) WUN_CWL(k, ss, 1, 3, 1) WUN_CWL(k, ss, 1, 4, 1) WUN_CWL(k, ss, 1, 5, 1) WUN_CWL(k, ss, 2, 2, 1) WUN_CWL(k, ss, 2, 3, 1) \
+                           WUN_CWL(k, ss, 1, 2, 2) WUN_CWL(k, ss, 1, 3, 2) WUN_CWL(k, ss, 2, 2, 2) WUN_CWL(k, ss, 2, 3, 2)
+    WUN_CWL_ALL(15, 1) WUN_CWL_ALL(15, 2) WUN_CWL_ALL(5, 1)
+#undef WUN_CWL_ALL
 #undef WUN_CWL
     return hipErrorInvalidValue;
 }

@@ -348,7 +348,9 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
     for (int j = 0; j < L; ++j) p->up[j].wt_full = add_wt(p->up[j], Ku, Ku - 1, 1);
 
     // ---- exact fp32: window-layout copies for the register-window conv kernel (15- and 5-tap convs, >= 8 input channels) ----
-    if (cfg->compute_dtype != 1 && getenv("WUN_NO_CONV_WIN") == nullptr) {
+    // (opt-in, WUN_CONV_WIN=1: measured on par with conv_mfma_kernel per launch and 0.5 % slower per step with its weight
+    //  pre-pass on the chain -- DESIGN.md section 5f; the tiles stay reachable through the operator test hooks)
+    if (cfg->compute_dtype != 1 && getenv("WUN_CONV_WIN") != nullptr && atoi(getenv("WUN_CONV_WIN")) != 0) {
         auto add_win = [&](int in_ws, long long src_off, int K, int Cin, int Nout) {
             if (!(K == 15 || K == 5) || Cin < 8 || (Cin & 3) || (Nout & 3) || Nout < 16) return;
             WinPackDesc d;
