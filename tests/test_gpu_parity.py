@@ -695,44 +695,64 @@ def test_autotuned_full_size_m1_context(lib):
     _grad_check(sep, tp, ograds, tag="autotuned_M1_context_full_B2")
 
 
-def test_tuned_plan_error_is_not_systematic(lib):
-    """A float32 evaluation of this network sits 1e-4 .. 5e-4 (of max|g|) away from float64 on a FEW weight-gradient
-    tensors whenever the sign of a near-zero LeakyReLU input in a deep layer comes out differently (the derivative
-    jumps 0.2 -> 1; tools/lrelu_flip_study.py shows the torch-CPU float32 oracle doing the same under 3e-7 input
-    perturbations, profiles/round4_lrelu_flip_study_B2.json).  Such an error moves with the last bits of the input; a
-    kernel bug (a dropped boundary position has the same size) does not.  So: the autotuned full-size M1 + context plan
-    on three copies of the batch that differ by ~3e-7 -- every gradient tensor's MEDIAN error over the three runs must
-    be at the rounding level (2e-5), every single run within GRAD_TOL."""
+def test_tuned_plan_error_is_the_leaky_relu_sign_floor(lib):
+    """Where an autotuned plan sits 1e-4 .. 5e-4 (of max|g|) from float64 on some weight gradients, the cause is ONE (or a
+    few) LeakyReLU input within float32 rounding of zero whose sign -- hence a factor 5 on that element's gradient --
+    depends on the summation order of the forward conv that produced it (profiles/round4_wsdiff_single_mask_flip.txt:
+    one element of the workspace differs by exactly 5x between two plans; profiles/round4_lrelu_flip_study_B2.json: the
+    torch-CPU float32 oracle jumps by 2e-4 under 3e-7 input perturbations).  A kernel bug of the same size (a dropped
+    boundary position) would NOT disappear when the masks are pinned.  So, on the full-size M1 + context plan:
+      * tuned backward kernels (input + weight gradients) on the HEURISTIC forward pass (tuned table with its forward
+        entries reset): every gradient tensor within 2e-5 of float64 -- the tuned backward kernels are exact;
+      * the fully tuned plan: outputs within OUT_TOL (its forward kernels differ from the heuristic ones by rounding
+        only), gradients within GRAD_TOL."""
     ocfg = shapes.finalize_config(dict(shapes.BASE_MODEL_CONFIG, context=True))
     params = golden_params(ocfg, 77)
-    sep = UnetAudioSeparator(wun.get_config("m1_context"), device="cuda:0")
     B = 2
     i, o = shapes.get_padding(ocfg, [B, 16384, 0])
     mix, targets = wt.synthetic_batch(ocfg, B, i[1], o[1], seed=78)
-    sep._plan(B, i[1]); sep._active = sep._plans[(B, i[1])]
-    sep.load_variables(params)
     tg = {k: torch.from_numpy(v) for k, v in targets.items()}
-    sep.tune(torch.from_numpy(mix).cuda(), tg)
-    rng = np.random.default_rng(11)
-    errs = []
-    for t in range(3):
-        m = mix if t == 0 else (mix * (1.0 + 3e-7 * rng.standard_normal(mix.shape))).astype(np.float32)
-        sep.get_output(torch.from_numpy(m).cuda(), True)
-        sep.loss_and_gradients(tg)
-        torch.cuda.synchronize()
-        _, ograds, _, tp = _oracle64(ocfg, params, m, targets)
-        g = sep.gradients()
-        row = []
+    dmix = torch.from_numpy(mix).cuda()
+    oloss, ograds, oouts, tp = _oracle64(ocfg, params, mix, targets)
+    names = ocfg["source_names"]
+
+    def fresh():
+        sep = UnetAudioSeparator(wun.get_config("m1_context"), device="cuda:0")
+        sep._plan(B, i[1]); sep._active = sep._plans[(B, i[1])]
+        sep.load_variables(params)
+        return sep
+
+    sep = fresh()
+    sep.tune(dmix, tg)
+    table = sep.tune_export()
+    lines = table.strip().split("\n")
+    fwd_reset = lines[0] + "\n" + "\n".join("cf -1 0" if ln.startswith("cf ") else ln for ln in lines[1:]) + "\n"
+
+    def worst_grad_err(s_):
+        g = s_.gradients()
+        w = 0.0
         for (n, _), og in zip(tp, ograds):
             got = g[n].cpu().double(); og = og.double()
-            row.append((got - og).abs().max().item() / max(og.abs().max().item(), 1e-30))
-        errs.append(row)
-    errs = np.array(errs)
-    med = np.median(errs, axis=0)
-    record("gradients_vs_float64_oracle", "tuned_M1_context_B2 median over 3 perturbed batches (worst tensor)", float(med.max()), 2e-5)
-    record("gradients_vs_float64_oracle", "tuned_M1_context_B2 worst single run", float(errs.max()), GRAD_TOL)
-    assert med.max() <= 2e-5, med.max()
-    assert errs.max() <= GRAD_TOL, errs.max()
+            w = max(w, (got - og).abs().max().item() / max(og.abs().max().item(), 1e-30))
+        return w
+
+    sep2 = fresh()
+    sep2.get_output(dmix, True)
+    sep2.tune_import(fwd_reset)
+    sep2.get_output(dmix, True)
+    sep2.loss_and_gradients(tg)
+    torch.cuda.synchronize()
+    e_bwd = worst_grad_err(sep2)
+    record("gradients_vs_float64_oracle", "tuned backward kernels on the heuristic forward pass, M1_context_B2", e_bwd, 2e-5)
+    assert e_bwd <= 2e-5, e_bwd
+
+    outs = sep.get_output(dmix, True)
+    sep.loss_and_gradients(tg)
+    torch.cuda.synchronize()
+    _out_check(outs, oouts, names, "fully_tuned_M1_context_B2")
+    e_all = worst_grad_err(sep)
+    record("gradients_vs_float64_oracle", "fully tuned plan, M1_context_B2 (LeakyReLU sign floor)", e_all, GRAD_TOL)
+    assert e_all <= GRAD_TOL, e_all
 
 
 def test_benchmarked_configuration_b16_tuned_vs_oracle(lib):

@@ -169,11 +169,13 @@ static long long bump(long long& cur, long long n) {
     return off;
 }
 
-static Buf make_buf(long long& cur, int B, int C, int T) {
+static Buf make_buf(long long& cur, int B, int C, int T, const char* name = nullptr, int idx = 0) {
     Buf b;
     b.C = C; b.T = T; b.pitch = (T + 3) / 4 * 4;
     b.bs = (long long)C * b.pitch;
     b.off = bump(cur, (long long)B * b.bs);
+    if (name != nullptr && getenv("WUN_DUMP_LAYOUT") != nullptr)      // (tools/ws_diff.py: workspace map for debugging)
+        fprintf(stderr, "[wun-layout] %s %d off=%lld B=%d C=%d T=%d pitch=%d\n", name, idx, b.off, B, C, T, b.pitch);
     return b;
 }
 
@@ -288,22 +290,22 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
     // ---- workspace ----
     long long w = 0;
     const int B = p->B;
-    p->mix_ncw = make_buf(w, B, C, p->Tin);
+    p->mix_ncw = make_buf(w, B, C, p->Tin, "mix_ncw");
     p->dec.resize(L); p->skip.resize(L); p->dz_dec.resize(L); p->dz_skip.resize(L);
     for (int i = 0; i < L; ++i) {
-        p->dec[i] = make_buf(w, B, p->dsh[i].cout, p->dsh[i].t_dec);
-        p->skip[i] = make_buf(w, B, p->dsh[i].cout, p->dsh[i].tc);
-        if (!same) p->dz_dec[i] = make_buf(w, B, p->dsh[i].cout, p->dsh[i].t_dec);
-        p->dz_skip[i] = make_buf(w, B, p->dsh[i].cout, p->dsh[i].tc);
+        p->dec[i] = make_buf(w, B, p->dsh[i].cout, p->dsh[i].t_dec, "dec", i);
+        p->skip[i] = make_buf(w, B, p->dsh[i].cout, p->dsh[i].tc, "skip", i);
+        if (!same) p->dz_dec[i] = make_buf(w, B, p->dsh[i].cout, p->dsh[i].t_dec, "dz_dec", i);
+        p->dz_skip[i] = make_buf(w, B, p->dsh[i].cout, p->dsh[i].tc, "dz_skip", i);
     }
-    p->bott_out = make_buf(w, B, p->c_b, p->t_b);
-    p->dz_bott = make_buf(w, B, p->c_b, p->t_b);
+    p->bott_out = make_buf(w, B, p->c_b, p->t_b, "bott_out");
+    p->dz_bott = make_buf(w, B, p->c_b, p->t_b, "dz_bott");
     p->ups.resize(L); p->upo.resize(L); p->d_ups.resize(L); p->dz_upo.resize(L);
     for (int j = 0; j < L; ++j) {
-        p->ups[j] = make_buf(w, B, p->ush[j].c_cur, p->ush[j].t_up);
-        p->d_ups[j] = make_buf(w, B, p->ush[j].c_cur, p->ush[j].t_up);
-        p->upo[j] = make_buf(w, B, p->ush[j].cout, p->ush[j].t_conv);
-        p->dz_upo[j] = make_buf(w, B, p->ush[j].cout, p->ush[j].t_conv);
+        p->ups[j] = make_buf(w, B, p->ush[j].c_cur, p->ush[j].t_up, "ups", j);
+        p->d_ups[j] = make_buf(w, B, p->ush[j].c_cur, p->ush[j].t_up, "d_ups", j);
+        p->upo[j] = make_buf(w, B, p->ush[j].cout, p->ush[j].t_conv, "upo", j);
+        p->dz_upo[j] = make_buf(w, B, p->ush[j].cout, p->ush[j].t_conv, "dz_upo", j);
     }
     p->dp_pitch = (p->Tout + 3) / 4 * 4;
     p->dpre_off = bump(w, (long long)p->Sh * B * C * p->dp_pitch);
