@@ -7,7 +7,7 @@ tag=${1:-round}
 R=$PWD
 mkdir -p gpurun_out
 # tilings: bench.py imports the committed pinned table of the config by itself (read-only); PINNED=0 -> fresh tuning
-PIN=$R/profiles/round3_tune_table.txt
+PIN=$R/profiles/round4_tune_table.txt
 if [ "${PINNED:-1}" != 1 ]; then
     export WUN_TUNE_CACHE=$R/gpurun_out/${tag}_tune_table.txt
     [ "${KEEP_TUNE:-0}" = 1 ] || rm -f $WUN_TUNE_CACHE

@@ -8,7 +8,7 @@ table, takes for every launch position the near-best candidates the library logg
 coordinate descent on the median step time: a change is kept if it improves the median of `--steps` steps by more
 than `--gain` and the improvement is confirmed by a second measurement against the incumbent.
 
-usage: python tools/step_tune.py --out profiles/round3_tune_table.txt [--config m1_context] [--passes 2]
+usage: python tools/step_tune.py --out profiles/round4_tune_table.txt [--config m1_context] [--passes 2]
 (runs on the GPU box; ~1 minute per pass)"""
 import argparse
 import os
