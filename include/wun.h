@@ -222,11 +222,13 @@ int wun_op_force_wgrad_variant(int mtw, int nw, int nsplit);
  * to bf16, v_mfma_f32_16x16x32_bf16, fp32 accumulate; same tiles / splits / reduction). */
 int wun_op_set_wgrad_bf16(int on);
 
-/* Test hook: run the following (exact-fp32) wun_op_conv1d_wgrad calls on the ping-pong form of the weight-gradient
- * kernel (one 512-thread workgroup per CU whose two wave sets alternate between staging a unit and multiplying the
- * previous one; same tiles, partial layout and reduction; additionally mtw = 6 with nw in {4, 5}).  Ignored while the
+/* Test hook: run the following (exact-fp32) wun_op_conv1d_wgrad calls on the register-window form of the weight-gradient
+ * kernel (wgrad_win_kernel: aligned 16-byte operand reads, DMA staging issued from inside the MFMA stream, split partials
+ * in the final [K][Cin][Cout] layout) -- the form the plan uses for every layer it serves.  wun_op_force_wgrad_variant then
+ * means (1, column tiles per wave 1..5|6, splits; a negative split count = target grid size).  Shapes the kernel does not
+ * serve (taps other than 15 / 5; 15 taps with Cin not a multiple of 8) fail with WUN_ERR_UNSUPPORTED.  Ignored while the
  * bf16 hook is on. */
-int wun_op_set_wgrad_pp(int on);
+int wun_op_set_wgrad_win(int on);
 
 /* The bf16 speed mode's conv as a single operator (wun_op_conv1d semantics, Cin >= 8, K <= 15): operands
  * are rounded to bf16 (nearest-even), products accumulate in fp32.  scratch: device floats, at least

@@ -216,3 +216,53 @@ def test_sharded_validation_failure_on_any_rank_raises_on_every_rank(tmp_path):
     for r in (0, 1):
         got = open(os.path.join(str(tmp_path), "r%d.txt" % r)).read()
         assert got.startswith("ERR sharded validation failed") and "rank 1: ValueError: bad track" in got, (r, got)
+
+
+def _rank0_checkpoint_worker(rank, world, port, out_dir, corrupt):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    init_distributed(backend="gloo")
+    import torch
+    from wave_u_net_amd import validation
+
+    class FakeSeparator:                         # the arena of a separator, without the HIP library
+        def __init__(self, cfg):
+            self.params = None
+
+        def variables(self):
+            if self.params is None:
+                self.params = torch.full((8,), float(-1 - rank))
+            return {}
+
+    loads = []
+
+    def fake_load(sep, path):
+        loads.append(path)
+        if corrupt:
+            raise OSError("truncated file")
+        sep.params.copy_(torch.arange(8, dtype=torch.float32))
+        return 7
+
+    validation._load_checkpoint = fake_load
+    sep, err = validation._load_on_rank0_and_broadcast({}, "/only/on/rank0.npz", make_separator=FakeSeparator)
+    with open(os.path.join(out_dir, "r%d.txt" % rank), "w") as f:
+        f.write("%s|%s|%s" % (sep.params.tolist(), err, loads))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_validation_reads_the_checkpoint_on_rank0_only(tmp_path):
+    """Only rank 0 is guaranteed to have the checkpoint path (no shared file system): it loads, the parameters are
+    broadcast; a load failure reaches every rank as text instead of leaving them in the broadcast."""
+    port = _free_port()
+    mp.spawn(_rank0_checkpoint_worker, args=(2, port, str(tmp_path), False), nprocs=2, join=True)
+    want = str([float(i) for i in range(8)])
+    r0 = open(os.path.join(str(tmp_path), "r0.txt")).read().split("|")
+    r1 = open(os.path.join(str(tmp_path), "r1.txt")).read().split("|")
+    assert r0[0] == r1[0] == want and r0[1] == r1[1] == "None"
+    assert r0[2] == "['/only/on/rank0.npz']" and r1[2] == "[]"
+    port = _free_port()
+    mp.spawn(_rank0_checkpoint_worker, args=(2, port, str(tmp_path), True), nprocs=2, join=True)
+    for r in (0, 1):
+        got = open(os.path.join(str(tmp_path), "r%d.txt" % r)).read().split("|")
+        assert "could not be loaded on rank 0: OSError: truncated file" in got[1], got

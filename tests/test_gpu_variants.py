@@ -391,3 +391,79 @@ def test_wgrad_every_geometry_and_split(lib, case):
 def test_every_wgrad_geometry_was_exercised(lib):
     missing = [g for g in WGRAD_GEOMS if g not in _RAN_WGRAD]
     assert not missing, "wgrad_mfma_kernel<MTW, NW> instantiations never checked: %s" % missing
+
+
+# ---- register-window weight-gradient kernel (wun_wgrad_win.hip): every instantiation <K, NW, S> x split counts ----
+WIN_WGRAD_CASES = [
+    # (B, Cin, Cout, K, T, stride, pad_left, same)
+    (2, 24, 48, 15, 1400, 1, 0, False),
+    (2, 24, 80, 15, 1401, 2, 0, False),
+    (16, 48, 56, 15, 95, 2, 0, False),
+    (3, 64, 72, 15, 23, 1, 7, True),            # same padding: zero columns on both sides of every row
+    (2, 40, 24, 5, 300, 1, 2, True),
+    (2, 72, 100, 5, 517, 1, 0, False),
+]
+_RAN_WIN = set()
+
+
+@pytest.mark.parametrize("case", WIN_WGRAD_CASES, ids=[str(c) for c in WIN_WGRAD_CASES])
+def test_window_wgrad_every_instantiation_and_split(lib, case):
+    """wun_op_set_wgrad_win(1): the same operator on wgrad_win_kernel<K, NW, S> (+ wgrad_win_reduce_kernel) for every column
+    tile count, with the split count chosen by the library, 1, and a target grid of 512 workgroups."""
+    B, Cin, Cout, K, T, stride, pad, same = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31) + 13)
+    x = rng.uniform(-1, 1, (B, Cin, T)).astype(np.float32)
+    t_out = _t_out(T, K, stride, same)
+    dz = rng.uniform(-1, 1, (B, Cout, t_out)).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64)
+    wtn = torch.zeros((K, Cin, Cout), dtype=torch.float64, requires_grad=True)
+    need = (t_out - 1) * stride + K - pad
+    xp = F.pad(xt, (pad, max(0, need - T)))
+    y = F.conv1d(xp, wtn.permute(2, 1, 0), None, stride=stride)[:, :, :t_out]
+    (y * torch.tensor(dz, dtype=torch.float64)).sum().backward()
+    ref_dw = wtn.grad.numpy()
+    ref_db = dz.astype(np.float64).sum(axis=(0, 2))
+    sw, sb = max(1.0, np.abs(ref_dw).max()), max(1.0, np.abs(ref_db).max())
+    dxg, dzg = _cuda(x), _cuda(dz)
+    ran, worst = 0, 0.0
+    _lib.check(lib.wun_op_set_wgrad_win(1))
+    try:
+        for nw in range(1, 7 if K == 5 else 6):
+            for ns in (0, 1, -512):
+                lib.wun_op_force_wgrad_variant(1, nw, ns)
+                scr = torch.empty(int(lib.wun_op_conv1d_wgrad_scratch(B, Cin, Cout, K, t_out)), device="cuda")
+                gdw = torch.full((K, Cin, Cout), float("nan"), device="cuda")
+                gdb = torch.full((Cout,), float("nan"), device="cuda")
+                rc = lib.wun_op_conv1d_wgrad(dxg.data_ptr(), dzg.data_ptr(), gdw.data_ptr(), gdb.data_ptr(),
+                                             scr.data_ptr(), B, Cin, Cout, K, T, t_out, stride, pad, _stream())
+                _lib.check(rc)
+                torch.cuda.synchronize()
+                ew = np.abs(gdw.cpu().numpy() - ref_dw).max() / sw
+                eb = np.abs(gdb.cpu().numpy() - ref_db).max() / sb
+                assert ew <= OP_TOL and eb <= OP_TOL, (nw, ns, ew, eb)
+                worst = max(worst, ew, eb)
+                _RAN_WIN.add((K, min(nw, (Cout + 15) // 16), stride))
+                ran += 1
+    finally:
+        lib.wun_op_force_wgrad_variant(0, 0, 0)
+        lib.wun_op_set_wgrad_win(0)
+    assert ran >= 15
+    record("window_wgrad_every_instantiation_and_split", str(case), worst, OP_TOL)
+
+
+def test_window_wgrad_refuses_what_it_does_not_serve(lib):
+    """Tap counts other than 15 / 5 (and K = 15 with a channel count that is not a multiple of 8) are refused with
+    WUN_ERR_UNSUPPORTED while the hook is on -- never computed by another kernel behind the caller's back."""
+    _lib.check(lib.wun_op_set_wgrad_win(1))
+    try:
+        for (Cin, K) in ((24, 9), (20, 15)):
+            B, Cout, T = 2, 32, 200
+            t_out = T - K + 1
+            x = torch.zeros(B, Cin, T, device="cuda"); dz = torch.zeros(B, Cout, t_out, device="cuda")
+            dw = torch.zeros(K, Cin, Cout, device="cuda"); db = torch.zeros(Cout, device="cuda")
+            scr = torch.empty(max(int(lib.wun_op_conv1d_wgrad_scratch(B, Cin, Cout, K, t_out)), 1), device="cuda")
+            rc = lib.wun_op_conv1d_wgrad(x.data_ptr(), dz.data_ptr(), dw.data_ptr(), db.data_ptr(), scr.data_ptr(),
+                                         B, Cin, Cout, K, T, t_out, 1, 0, _stream())
+            assert rc == -2, (Cin, K, rc)
+    finally:
+        lib.wun_op_set_wgrad_win(0)

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Op-level A/B of the weight-gradient kernels on the layer shapes of the headline configuration (B = 16):
-wgrad_mfma_kernel (two 256-thread workgroups per CU) against wgrad_pp_kernel (one 512-thread ping-pong workgroup),
-interleaved round-robin, kernel times from the library's HIP-event brackets (wgrad + its split reduction).
-usage: python tools/wgrad_pp_bench.py [shape-filter] [rounds]"""
+the LDS-tiled wgrad_mfma_kernel (every geometry x split targets) against the register-window wgrad_win_kernel (target
+grids 256 .. 2048), interleaved round-robin, kernel times from the library's HIP-event brackets (wgrad + its split
+reduction).
+usage: python tools/wgrad_win_bench.py [shape-filter] [rounds]"""
 import ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -36,27 +37,27 @@ def main():
         M = Cin * K + 1
         cands = [("old", 0, 0, 0, 0)]
         nws = sorted(set(nw for nw in range(1, 6) if ((Cout + 16 * nw - 1) // (16 * nw)) * 16 * nw <= 1.2 * Cout + 8))
-        for pp in (0,):
+        for win in (0,):
             for mtw in (6, 4, 2):
                 if M <= 64 * (mtw // 2) and mtw > 2:
                     continue
                 for nw in nws:
                     per = ((M + 64 * mtw - 1) // (64 * mtw)) * ((Cout + 16 * nw - 1) // (16 * nw))
-                    for tgt in ((256, 512, 768, 1024) if pp else (512, 1024)):
+                    for tgt in (512, 1024):
                         ns = max(1, tgt // per)
-                        cands.append(("pp" if pp else "mf", mtw, nw, ns, pp))
-        if os.environ.get("PP_ONLY_WIN"):
+                        cands.append(("mf", mtw, nw, ns, win))
+        if os.environ.get("ONLY_WIN"):
             cands = [c for c in cands if c[0] == "old" or (c[0] == "mf" and c[3] in (0,))][:1]
         tiles_guess = 1
         for tgt in (256, 512, 768, 1024, 1536, 2048):
-            cands.append(("win", 0, 0, -tgt, 2))
+            cands.append(("win", 0, 0, -tgt, 1))
         cands = list(dict.fromkeys(cands))
         res = {}
         ref = None
         live = []
         for c in cands:
-            kind, mtw, nw, ns, pp = c
-            lib.wun_op_set_wgrad_pp(pp)
+            kind, mtw, nw, ns, win = c
+            lib.wun_op_set_wgrad_win(win)
             lib.wun_op_force_wgrad_variant(mtw, nw, ns)
             if kind == "win":
                 lib.wun_op_force_wgrad_variant(0, 0, -(1 << 14))
@@ -78,8 +79,8 @@ def main():
             res[c] = []
         for r in range(rounds):
             for (c, scr, err) in live:
-                kind, mtw, nw, ns, pp = c
-                lib.wun_op_set_wgrad_pp(pp)
+                kind, mtw, nw, ns, win = c
+                lib.wun_op_set_wgrad_win(win)
                 lib.wun_op_force_wgrad_variant(mtw, nw, ns)
                 lib.wun_profile_begin()
                 for _ in range(3):
@@ -90,11 +91,11 @@ def main():
                 _lib.check(lib.wun_profile_end(buf, len(buf)))
                 pj = json.loads(buf.value.decode())
                 ovh = pj.get("bracket_overhead_ms", 0.0)
-                wg = sum(k["ms"] / k["launches"] - ovh for k in pj["kernels"] if k["name"].startswith("wgrad_mfma") or k["name"].startswith("wgrad_pp") or k["name"].startswith("wgrad_win_kernel"))
+                wg = sum(k["ms"] / k["launches"] - ovh for k in pj["kernels"] if k["name"].startswith("wgrad_mfma") or k["name"].startswith("wgrad_win_kernel"))
                 rd = sum(k["ms"] / k["launches"] - ovh for k in pj["kernels"] if k["name"].startswith("wgrad_reduce") or k["name"].startswith("wgrad_win_reduce"))
-                nm = [k["name"] for k in pj["kernels"] if k["name"].startswith("wgrad_mfma") or k["name"].startswith("wgrad_pp") or k["name"].startswith("wgrad_win_kernel")][0]
+                nm = [k["name"] for k in pj["kernels"] if k["name"].startswith("wgrad_mfma") or k["name"].startswith("wgrad_win_kernel")][0]
                 res[c].append((wg, rd, nm))
-        lib.wun_op_set_wgrad_pp(0)
+        lib.wun_op_set_wgrad_win(0)
         lib.wun_op_force_wgrad_variant(0, 0, 0)
         rows = []
         for (c, scr, err) in live:
@@ -106,11 +107,11 @@ def main():
         for tot, wg, rd, c, nm, err in rows[:8]:
             print("   %-28s ns=%-4d wg %7.1f us  red %5.1f us  tot %7.1f  %6.1f TF  (x%.2f vs old) err %.1e" % (
                 nm, c[3], wg * 1e3, rd * 1e3, tot * 1e3, flops / wg / 1e9, base[0] / tot, err))
-        bestpp = [r for r in rows if r[3][0] == "win"]
+        bestwin = [r for r in rows if r[3][0] == "win"]
         bestmf = [r for r in rows if r[3][0] in ("mf", "old")]
         out.append({"shape": name, "old_us": base[0] * 1e3, "best_mf_us": bestmf[0][0] * 1e3 if bestmf else None,
-                    "best_pp_us": bestpp[0][0] * 1e3 if bestpp else None,
-                    "best_pp": bestpp[0][3] if bestpp else None, "max_err_pp": max([r[5] for r in bestpp] or [0])})
+                    "best_win_us": bestwin[0][0] * 1e3 if bestwin else None,
+                    "best_win": bestwin[0][3] if bestwin else None, "max_err_win": max([r[5] for r in bestwin] or [0])})
         sys.stdout.flush()
     print(json.dumps(out))
 

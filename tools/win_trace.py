@@ -14,7 +14,7 @@ T = (Tq - 1) * stride + K
 x = torch.rand(B, Cin, T, device="cuda") * 2 - 1
 dz = torch.rand(B, Cout, Tq, device="cuda") * 2 - 1
 dw = torch.empty(K, Cin, Cout, device="cuda"); db = torch.empty(Cout, device="cuda")
-lib.wun_op_set_wgrad_pp(2)
+lib.wun_op_set_wgrad_win(1)
 lib.wun_op_force_wgrad_variant(0, 0, -tgt)
 n = lib.wun_op_conv1d_wgrad_scratch(B, Cin, Cout, K, Tq)
 scr = torch.empty(int(n), device="cuda")

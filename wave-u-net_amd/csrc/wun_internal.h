@@ -103,16 +103,13 @@ struct WgradArgs {
     int ablate;      // debugging switches (only read when built with -DWUN_ABLATION)
     int force_mtw, force_nw;   // autotuner: geometry overrides (0 = heuristic)
     int bf16;        // speed mode: operands rounded to bf16 in LDS, v_mfma_f32_16x16x32_bf16 (wun_wgrad_bf16.hip)
-    int pp;          // exact fp32, ping-pong form: one 512-thread workgroup per CU, two wave sets alternate staging / MFMA (wun_wgrad_pp.hip)
+    int win;         // exact fp32, register-window form (wun_wgrad_win.hip) instead of the LDS-tiled wgrad_mfma_kernel
 };
-    // (WgradArgs.pp == 2: the register-window kernel of wun_wgrad_win.hip)
-#define WUN_WG_PP_XIT 12   // float4 input loads per thread and unit of the ping-pong kernel (no staging registers live across MFMAs)
 
 // tile geometry of an exact-fp32 weight-gradient launch
 struct WgradGeom { int MTW, NW, nMG, nNG, TK, XP, ZP, nChMax, ONESP, XW4; size_t lds; };
 WgradGeom wgrad_geom(const WgradArgs& a);
-hipError_t launch_wgrad_pp(const WgradArgs& a, const WgradGeom& g, hipStream_t s);
-// register-window weight gradient (wun_wgrad_win.hip; WgradArgs.pp == 2): aligned 16-byte operand reads, DMA staging,
+// register-window weight gradient (wun_wgrad_win.hip; WgradArgs.win): aligned 16-byte operand reads, DMA staging,
 // split partials in the final layout
 bool wgrad_win_supported(const WgradArgs& a);
 long long wgrad_win_partial_floats(const WgradArgs& a);

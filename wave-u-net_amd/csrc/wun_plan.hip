@@ -715,8 +715,10 @@ static hipError_t conv_dispatch(const wun_plan* p, ConvArgs a, float* part, long
     }
     if (p->tune_mode == 1) {
         if (vec.size() <= idx) vec.resize(idx + 1, ConvChoice{-1, 0});
-        static ConvChoice cands[640];
-        static float tms[641];
+        std::vector<ConvChoice> cands_v(640);               // (per call: two plans may be tuned from different threads)
+        std::vector<float> tms_v(641);
+        ConvChoice* cands = cands_v.data();
+        float* tms = tms_v.data();
         const int n = conv_list_candidates(a, part ? cap : 0, cands, 640);
         // candidate n = the heuristic choice (the baseline); a candidate has to beat it by > 2 %
         time_candidates(p, s, n + 1, [&](int i) {
@@ -972,9 +974,9 @@ static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const Conv
     // in whole row tiles); its split partials are in the final layout, so the parts need not share a tile geometry
     static const bool no_win = getenv("WUN_NO_WIN") != nullptr;
     bool win_ok = !no_win && !parts[0].bf16;
-    for (int i = 0; i < nparts && win_ok; ++i) { WgradArgs t = parts[i]; t.pp = 2; win_ok = wgrad_win_supported(t); }
+    for (int i = 0; i < nparts && win_ok; ++i) { WgradArgs t = parts[i]; t.win = 1; win_ok = wgrad_win_supported(t); }
     auto set_win = [&](WgradArgs* q, int cgw, int nw) {
-        for (int i = 0; i < nparts; ++i) { q[i].pp = 2; q[i].force_mtw = cgw; q[i].force_nw = nw; }
+        for (int i = 0; i < nparts; ++i) { q[i].win = 1; q[i].force_mtw = cgw; q[i].force_nw = nw; }
     };
     if (win_ok) {
         set_win(parts, 0, 0);
@@ -1043,7 +1045,7 @@ static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const Conv
         for (int mi = 0; mi < 5; ++mi)
             for (int nw = 5; nw >= 1; --nw) {
                 if (nw > 3 && (mtws[mi] == 6 || parts[0].N <= 48)) continue;
-                for (int i = 0; i < nparts; ++i) { g[i] = parts[i]; g[i].pp = 0; }
+                for (int i = 0; i < nparts; ++i) { g[i] = parts[i]; g[i].win = 0; }
                 if (!wgrad_common_geom(g, nparts, mtws[mi], nw)) continue;
                 int m, n;
                 wgrad_resolved_geom(g[0], m, n);
@@ -1102,7 +1104,7 @@ static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const Conv
                        : ((c.mtw == 1 || c.mtw == 2 || c.mtw == 4 || c.mtw == 6 || c.mtw == 8) && c.nw >= 1 && c.nw <= 5);
         for (int i = 0; ok && i < nparts; ++i) ok = c.nsplit[i] >= 1;
         WgradArgs g[2];
-        for (int i = 0; i < nparts; ++i) { g[i] = parts[i]; g[i].pp = 0; }
+        for (int i = 0; i < nparts; ++i) { g[i] = parts[i]; g[i].win = 0; }
         if (ok && cwin) {
             set_win(g, 1, c.nw);
             for (int i = 0; ok && i < nparts; ++i) ok = c.nsplit[i] <= wgrad_max_units(g[i]);
@@ -1467,7 +1469,10 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
                 set_dst0(f, ws, p->dz_dec[i - 1], 0, &p->dec[i - 1]);
                 const bool win_early = level_early(i) && !p->win_ev.empty();
                 if (win_early) {
-                    // the window part is already in dz_dec[i-1] (side stream): wait for it, add inside the window
+                    // the window part is already in dz_dec[i-1] (side stream): wait for it, add inside the window.  With
+                    // WUN_WG_BATCH > 1 its launch may still sit in the queue (win_ev[i] would be last step's record):
+                    // issue it now
+                    if (std::find(pend_win.begin(), pend_win.end(), i) != pend_win.end() && (rc = flush_wgrads())) return rc;
                     if (s2 != s) HIP_TRY(hipStreamWaitEvent(s, p->win_ev[(size_t)i], 0));
                     f.flags |= F_ACCUM; f.acc_lo = d.cs; f.acc_len = (unsigned)(d.tc + Kd - 1);
                 }
@@ -1534,7 +1539,13 @@ static std::string tune_header(const wun_plan* p, size_t ncf, size_t ncb, size_t
              WUN_TUNE_ORDER, conv_num_variants(), p->B, (long long)p->Tin, p->L, c.num_initial_filters, c.filter_size,
              c.merge_filter_size, c.output_filter_size, c.upsampling, c.output_type, c.context, c.num_sources,
              c.num_channels, c.output_activation, c.compute_dtype, (long long)p->arena, ncf, ncb, nwg);
-    return line;
+    std::string h = line;
+    // a non-default early-window mode changes the order of the backward conv launches: such tables only match themselves
+    if (const char* ew = getenv("WUN_EARLY_WINDOW")) {
+        if (ew[0] == '0') h += " ew=0";
+        else if (ew[0] == 'a') h += " ew=all";
+    }
+    return h;
 }
 
 extern "C" int wun_plan_tune_export(const wun_plan* p, char* buf, int64_t cap) {
@@ -1621,7 +1632,7 @@ static const long long kOpScratchFloats = 8ll << 20;
 static int g_op_variant = -1, g_op_ksplit = 0;          // wun_op_force_conv_variant (test hook)
 static int g_op_wg_mtw = 0, g_op_wg_nw = 0, g_op_wg_nsplit = 0;   // wun_op_force_wgrad_variant (test hook)
 static int g_op_wg_bf16 = 0;                                       // wun_op_set_wgrad_bf16 (test hook)
-static int g_op_wg_pp = 0;                                         // wun_op_set_wgrad_pp (test hook)
+static int g_op_wg_win = 0;                                        // wun_op_set_wgrad_win (test hook)
 static float* op_scratch() {
     static float* buf = nullptr;
     if (!buf && hipMalloc((void**)&buf, kOpScratchFloats * sizeof(float)) != hipSuccess) {
@@ -1694,12 +1705,12 @@ static WgradArgs op_wgrad_args(const float* x, const float* dz, int batch, int c
 static long long op_wgrad_part_floats(int batch, int cin, int cout, int k, int t_out, int loader) {
     WgradArgs a = wgrad_shape_only(batch, cin, 0, k, loader, cout, t_out);
     a.bf16 = (g_op_wg_bf16 && wgrad_bf16_supported(a)) ? 1 : 0;
-    a.pp = (g_op_wg_pp && !a.bf16) ? g_op_wg_pp : 0;
-    if (a.pp == 2 && !wgrad_win_supported(a)) a.pp = 0;
+    a.win = (g_op_wg_win && !a.bf16) ? 1 : 0;
+    if (a.win && !wgrad_win_supported(a)) a.win = 0;
     if (g_op_wg_mtw > 0) { a.force_mtw = g_op_wg_mtw; a.force_nw = g_op_wg_nw; }
     long long ns = wgrad_pick_nsplit(a);
     if (g_op_wg_nsplit > 0) ns = std::min(g_op_wg_nsplit, wgrad_max_units(a));
-    if (g_op_wg_nsplit < 0 && a.pp == 2) ns = std::min(std::max(1, -g_op_wg_nsplit / wgrad_win_tiles(a)), wgrad_max_units(a));
+    if (g_op_wg_nsplit < 0 && a.win) ns = std::min(std::max(1, -g_op_wg_nsplit / wgrad_win_tiles(a)), wgrad_max_units(a));
     return ns * wgrad_partial_floats(a);
 }
 
@@ -1731,8 +1742,8 @@ extern "C" int wun_op_conv1d_wgrad(const float* x, const float* dz, float* dw, f
     WgradArgs w = op_wgrad_args(xs, zs, batch, cin, cout, k, t_in, t_out, stride, pad_left, xp, zp);
     if (g_op_wg_bf16 && !wgrad_bf16_supported(w)) return fail(WUN_ERR_UNSUPPORTED, "shape not served by the bf16 weight-gradient kernel");
     w.bf16 = g_op_wg_bf16;
-    w.pp = (g_op_wg_pp && !w.bf16) ? g_op_wg_pp : 0;
-    if (w.pp == 2 && !wgrad_win_supported(w)) return fail(WUN_ERR_UNSUPPORTED, "shape not served by the register-window weight-gradient kernel");
+    w.win = (g_op_wg_win && !w.bf16) ? 1 : 0;
+    if (w.win && !wgrad_win_supported(w)) return fail(WUN_ERR_UNSUPPORTED, "shape not served by the register-window weight-gradient kernel");
     if (g_op_wg_mtw > 0) {
         w.force_mtw = g_op_wg_mtw; w.force_nw = g_op_wg_nw;
         int m, n;
@@ -1744,7 +1755,7 @@ extern "C" int wun_op_conv1d_wgrad(const float* x, const float* dz, float* dw, f
     if (g_op_wg_nsplit > 0) {
         w.nsplit = std::min(g_op_wg_nsplit, wgrad_max_units(w));
     }
-    if (g_op_wg_nsplit < 0 && w.pp == 2)       // (window kernel: a negative count is a target grid size)
+    if (g_op_wg_nsplit < 0 && w.win)       // (window kernel: a negative count is a target grid size)
         w.nsplit = std::min(std::max(1, -g_op_wg_nsplit / wgrad_win_tiles(w)), wgrad_max_units(w));
     part = (float*)(((uintptr_t)part + 255) & ~(uintptr_t)255);
     w.out = part; w.direct = 0; w.split_base = 0;      // always through the split reduction (dw and db are separate buffers)
@@ -1812,7 +1823,7 @@ extern "C" int wun_op_force_conv_variant(int variant, int ksplit) {
 extern "C" int wun_op_num_conv_variants(void) { return conv_num_variants(); }
 
 extern "C" int wun_op_set_wgrad_bf16(int on) { g_op_wg_bf16 = on ? 1 : 0; return WUN_OK; }
-extern "C" int wun_op_set_wgrad_pp(int mode) { g_op_wg_pp = (mode == 1 || mode == 2) ? mode : 0; return WUN_OK; }
+extern "C" int wun_op_set_wgrad_win(int on) { g_op_wg_win = on ? 1 : 0; return WUN_OK; }
 
 extern "C" int wun_op_force_wgrad_variant(int mtw, int nw, int nsplit) {
     g_op_wg_mtw = mtw; g_op_wg_nw = nw; g_op_wg_nsplit = nsplit;

@@ -97,6 +97,25 @@ def optimise(model_config, experiment_id, data=None, data_root=None, max_epochs=
     return best_model_path, test_loss
 
 
+def _load_on_rank0_and_broadcast(model_config, load_model, make_separator=None):
+    """-> (separator holding the checkpoint's parameters on every rank, error text or None).  Rank 0 reads the file;
+    a failure there is broadcast as text so that no rank is left waiting in the parameter broadcast."""
+    import torch.distributed as dist
+    from .parallel import broadcast_parameters
+    sep = (make_separator or UnetAudioSeparator)(model_config)
+    sep.variables()                                  # (creates the parameter arena)
+    box = [None]
+    if dist.get_rank() == 0:
+        try:
+            _load_checkpoint(sep, load_model)
+        except Exception as e:                       # noqa: BLE001 -- reported on every rank by the caller
+            box[0] = "checkpoint %s could not be loaded on rank 0: %s: %s" % (load_model, type(e).__name__, e)
+    dist.broadcast_object_list(box, src=0)
+    if box[0] is None:
+        broadcast_parameters(sep.params)
+    return sep, box[0]
+
+
 def _sharded_test(model_config, partition, model_folder, load_model, tracks):
     """model_config["validation"] = "sharded": rank r evaluates tracks[r::world] and the ranks all-reduce (sum of batch
     losses, batch count) -- no GPU idles through a validation pass and nothing waits in a broadcast for rank 0's whole
@@ -107,10 +126,18 @@ def _sharded_test(model_config, partition, model_folder, load_model, tracks):
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
     sums, err = (0.0, 0), None
+    # the checkpoint is read on rank 0 only -- the one rank train() guarantees to have the path; the file system need
+    # not be shared -- and its parameters are broadcast into every rank's separator
+    sep, load_err = None, None
+    if load_model is not None:
+        sep, load_err = _load_on_rank0_and_broadcast(model_config, load_model)
     try:
+        if load_err:
+            raise RuntimeError(load_err)
         mine = list(tracks)[rank::world]
         if mine:
-            sums = test(model_config, partition, model_folder, load_model, tracks=mine, return_sums=True)
+            sums = test(model_config, partition, model_folder, load_model if sep is None else None, tracks=mine,
+                        return_sums=True, separator=sep)
     except Exception as e:                           # noqa: BLE001 -- re-raised below, on EVERY rank
         err = "rank %d: %s: %s" % (rank, type(e).__name__, e)
     errs = [None] * world
