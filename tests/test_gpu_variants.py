@@ -76,6 +76,11 @@ SWEEP_CASES = [
     (2, 24, 48, 15, 814, False),
     (2, 48, 96, 15, 814, False),
     (2, 48, 80, 5, 404, False),
+    # the in-workgroup split-K tiles (conv_mfma_kernel<..., KG = 3>: whole 8-channel chunks in multiples of 3): short
+    # rows, wide layers -- what the deep levels look like
+    (16, 72, 48, 5, 40, False),
+    (16, 144, 64, 15, 60, False),
+    (4, 72, 96, 5, 100, False),
 ]
 
 

@@ -62,7 +62,7 @@ def main():
         cfg["deep_f32"]["value"], cfg["deep_f32"]["ms_per_step"], 100 * tf(cfg["deep_f32"]) / 157.3, tf(cfg["deep_f32"])))
     r.append("| same | 1 | bf16 mode | %.3g | %.1f | %.1f %% of 6.9e8 | — | — |" % (cfg["deep_bf16"]["value"], cfg["deep_bf16"]["ms_per_step"],
                                                                              100 * cfg["deep_bf16"]["value"] / 6.9e8))
-    new = ("## 4. Results (round 3; 1×MI355X, B=16; `profiles/round4_bench.json`, `profiles/round4_cfg_*.json`)\n\n"
+    new = ("## 4. Results (round 4; 1×MI355X, B=16; `profiles/round4_bench.json`, `profiles/round4_cfg_*.json`)\n\n"
            "fp32 = the reference's arithmetic (exact-fp32 MFMA) — the only numbers comparable with the metric; bf16 mode = the speed mode of\n"
            "BASELINE.json configs[2], [4] (bf16 MFMA multiplicands, fp32 accumulate / storage / optimizer; DESIGN.md §5b), reported beside.\n\n"
            "| Config | GPUs | dtype | samples/s (out) | ms/step | fraction of the binding roofline | CPU baseline samples/s | speed-up |\n"

@@ -217,10 +217,16 @@ __device__ __forceinline__ int fast_div(int n, int d, float inv) {
 // unaligned test tensors.
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
-template <int MT, int NW, int WT, int WN, int CK, bool VECW, bool FOLD = false, bool XVEC = false>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int nNT, int J,
-                                                        int XP, int WP) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+// KG > 1 ("in-workgroup split-K", the deep levels): the workgroup is KG groups of 256 threads; group kg runs the whole
+// kernel body on its own LDS region for the channel chunks of sub-split ksg * KG + kg of the SAME output tile, the groups'
+// accumulators are summed through LDS in the fixed order ((g0 + g1) + g2) and group 0 runs the epilogue -- a launch with
+// few output tiles gets KG x the waves per tile without partial tiles in HBM or an epilogue launch on the dependent chain.
+// Every group runs the same number of chunks (launcher rule: chunks % (KG * splits) == 0), so the barriers stay uniform.
+template <int MT, int NW, int WT, int WN, int CK, bool VECW, bool FOLD = false, bool XVEC = false, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void conv_mfma_kernel(ConvArgs a, int nTT, int nNT, int J,
+                                                             int XP, int WP) {
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];
+    const int kg = KG > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;
     constexpr int TT = WT * MT * 16;
     constexpr int NT = WN * NW * 16;
     constexpr int NT4 = NT / 4;
@@ -241,10 +247,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
 
     // two LDS buffers {input window, weight slab}: chunk c+1 is written while chunk c is read
     const int XB = CK * XP, LB = CK * XP + J * CK * WP;      // floats per X tile / per buffer
+    float* lds = lds_all + (KG > 1 ? kg * 2 * LB : 0);
     float* Xs = lds;
     float* Ws = lds + XB;
 
-    const int tid = threadIdx.x;
+    const int tid = KG > 1 ? (int)(threadIdx.x & 255) : (int)threadIdx.x;
     const int lane = tid & 63;
     const int li = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -284,7 +291,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
     const int tt = bid % nTT; bid /= nTT;
     const float inv_tout = 1.0f / (float)a.Tout;
     const int b = FOLD ? fast_div(tt * TT, a.Tout, inv_tout) : bid % a.B;      // FOLD: first excerpt of the tile
-    const int ksp = FOLD ? bid : bid / a.B;
+    const int ksg = FOLD ? bid : bid / a.B;                   // split whose partial tile this workgroup produces
+    const int ksp = ksg * KG + kg;                            // sub-split of this group of 256 threads
     const int q0 = tt * TT, n0 = nt * NT;                     // FOLD: q0 = first flattened row
     // FOLD: excerpts touched by this tile and the per-excerpt segment length in the LDS row
     int fold_nb = 1;
@@ -724,6 +732,29 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
     WUN_TRACE_STAMP(2);
     WUN_PRIO_HI();
 
+    if constexpr (KG > 1) {
+        // ---- in-workgroup split-K: groups 1 .. KG-1 hand their accumulators over through LDS (the staging buffers are
+        // dead: barrier first), group 0 adds them in group order and carries on alone ----
+        __syncthreads();
+        float* red = lds_all;                                  // [KG - 1][MT * NW][256 threads] x 16 bytes
+        if (kg > 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NW; ++n)
+                    *reinterpret_cast<f32x4*>(&red[((((kg - 1) * MT + m) * NW + n) * 256 + tid) * 4]) = acc[m][n];
+        }
+        __syncthreads();
+        if (kg > 0) { WUN_TRACE_END(); return; }
+#pragma unroll
+        for (int g = 1; g < KG; ++g)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NW; ++n)
+                    acc[m][n] += *reinterpret_cast<const f32x4*>(&red[((((g - 1) * MT + m) * NW + n) * 256 + tid) * 4]);
+    }
+
     // ---- split-K: raw partial tile, epilogue runs in conv_splitk_epilogue_kernel ----
     if (a.part != nullptr) {
         const int TP = (a.Tout + 3) & ~3;
@@ -731,7 +762,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
         for (int n = 0; n < NW; ++n) {
             const int ncol = n0 + wn0 + n * 16 + li;
             if (ncol >= a.N) continue;
-            float* prow = a.part + (((long long)ksp * a.B + b) * a.N + ncol) * TP;
+            float* prow = a.part + (((long long)ksg * a.B + b) * a.N + ncol) * TP;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const int q = q0 + wt0 + m * 16 + lg * 4;
@@ -739,7 +770,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int nTT, int
                     int g = fast_div(q, a.Tout, inv_tout), qq = q - g * a.Tout;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        if (g < a.B) a.part[(((long long)ksp * a.B + g) * a.N + ncol) * TP + qq] = acc[m][n][r];
+                        if (g < a.B) a.part[(((long long)ksg * a.B + g) * a.N + ncol) * TP + qq] = acc[m][n][r];
                         if (++qq == a.Tout) { qq = 0; ++g; }
                     }
                 } else {
@@ -1127,6 +1158,16 @@ static const ConvVariant kConvVariants[] = {
 };
 #define WUN_FIRST_FOLD_VARIANT 34
 
+// In-workgroup split-K variants (conv_mfma_kernel<..., KG = 3>): variant WUN_FIRST_K3_VARIANT + i runs the tile of
+// kK3Base[i] with three 256-thread groups per workgroup.  3 divides the chunk count of every layer of this network
+// (channel counts are multiples of 24 = 3 chunks of 8), 4 does not.
+#define WUN_KG 3
+static const int kK3Base[] = {8, 9, 10, 11, 4, 5, 34, 35, 36, 37, 40};
+static const int kNumK3 = (int)(sizeof(kK3Base) / sizeof(kK3Base[0]));
+static int first_k3_variant();
+static inline bool is_k3(int v) { return v >= first_k3_variant() && v < first_k3_variant() + kNumK3; }
+static inline int conv_tile_variant(int v) { return is_k3(v) ? kK3Base[v - first_k3_variant()] : v; }   // index into kConvVariants
+
 // can this launch use FOLD variant `v`?  (segments of every excerpt a tile touches must fit the LDS row)
 static bool conv_fold_ok(const ConvArgs& a, int v) {
     const ConvVariant& cv = kConvVariants[v];
@@ -1238,6 +1279,12 @@ static inline long long conv_mtiles(const ConvArgs& a, int variant, int TT, int&
 }
 
 size_t conv_lds_bytes(const ConvArgs& a, int variant) {
+    if (is_k3(variant)) {
+        const int bv = conv_tile_variant(variant);
+        const size_t stage = WUN_KG * conv_lds_bytes(a, bv);
+        const size_t red = (size_t)(WUN_KG - 1) * kConvVariants[bv].MT * kConvVariants[bv].NW * 256 * 16;   // accumulator hand-over
+        return stage > red ? stage : red;
+    }
     if (variant >= WUN_FIRST_WIN_VARIANT) return conv_win_lds_bytes(a, variant - WUN_FIRST_WIN_VARIANT);
     int TT, NT, J, XP, WP;
     conv_geom(a, variant, TT, NT, J, XP, WP);
@@ -1272,7 +1319,7 @@ void conv_splitk(const ConvArgs& a, int variant, long long part_cap_floats, int&
     if (ksplit < 2) { ksplit = 1; cps = nchunks; }
 }
 
-template <int MT, int NW, int WT, int WN, int CK, bool VECW, bool FOLD = false, bool XVEC = false>
+template <int MT, int NW, int WT, int WN, int CK, bool VECW, bool FOLD = false, bool XVEC = false, int KG = 1>
 static hipError_t conv_launch_t(ConvArgs a, int variant, float* part, long long part_cap, hipStream_t s) {
     int TT, NT, J, XP, WP;
     conv_geom(a, variant, TT, NT, J, XP, WP);
@@ -1280,9 +1327,14 @@ static hipError_t conv_launch_t(ConvArgs a, int variant, float* part, long long 
     int bfac;
     const int nTT = (int)conv_mtiles(a, variant, TT, bfac);
     const int nNT = phase2 ? (a.N + NT / 2 - 1) / (NT / 2) : (a.N + NT - 1) / NT;
-    const size_t lds = conv_lds_bytes(a, variant);
+    size_t lds = conv_lds_bytes(a, variant);
+    if (KG > 1) {
+        const size_t red = (size_t)(KG - 1) * MT * NW * 256 * 16;
+        lds = KG * lds > red ? KG * lds : red;
+        if (phase2 || lds > 160 * 1024) return hipErrorInvalidValue;
+    }
     if (FOLD && !conv_fold_ok(a, variant)) return hipErrorInvalidValue;
-    auto kern = conv_mfma_kernel<MT, NW, WT, WN, CK, VECW, FOLD, XVEC>;
+    auto kern = conv_mfma_kernel<MT, NW, WT, WN, CK, VECW, FOLD, XVEC, KG>;
     static size_t lds_allowed = 64 * 1024;
     if (lds > lds_allowed) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1313,20 +1365,31 @@ static hipError_t conv_launch_t(ConvArgs a, int variant, float* part, long long 
         cps = (nchunks + want - 1) / want;
         ksplit = (nchunks + cps - 1) / cps;
     }
+    if (KG > 1) {
+        // every 256-thread group of every split gets the same whole number of chunks (uniform barriers)
+        const int CKC = a.loader == LOADER_DEINT ? CK / 2 : CK;
+        const int nchunks = (a.C0 + a.C1) / CKC;
+        const int want = (a.force_ksplit > 0 && part != nullptr) ? a.force_ksplit : 1;
+        if ((a.C0 + a.C1) % CKC != 0 || nchunks % (KG * want) != 0) return hipErrorInvalidValue;
+        const long long per = (long long)a.B * a.N * ((a.Tout + 3) & ~3);
+        if (want > 1 && (long long)want * per > part_cap) return hipErrorInvalidValue;
+        ksplit = want;
+        cps = nchunks / (KG * want);
+    }
     a.cps = cps;
     a.part = ksplit > 1 ? part : nullptr;
     const long long grid = (long long)nTT * nNT * bfac * ksplit;
     if (grid <= 0) return hipSuccess;
     char nm[64];
-    snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %s%s%s>", MT, NW, WT, WN, CK, VECW ? "true" : "false",
-             FOLD ? ", fold" : "", XVEC ? ", dma" : "");
+    snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %s%s%s%s>", MT, NW, WT, WN, CK, VECW ? "true" : "false",
+             FOLD ? ", fold" : "", XVEC ? ", dma" : "", KG > 1 ? ", k3" : "");
     {
         char tag[160];
         snprintf(tag, sizeof(tag), "C=%d N=%d T=%d K=%d ld=%d B=%d ks=%d ph2=%d acc=%d os=%d grid=%lld", a.C0 + a.C1, a.N,
                  a.Tout, a.KW, a.loader, a.B, ksplit, (a.flags & F_PHASE2) ? 1 : 0, (a.flags & F_ACCUM) ? 1 : 0,
                  a.ostride, grid);
         ProfScope ps(nm, conv_flops(a), s, tag);
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_launch, s, a, nTT, nNT, J, XP, WP);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256 * KG), lds_launch, s, a, nTT, nNT, J, XP, WP);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || ksplit == 1) return e;
@@ -1350,6 +1413,25 @@ static hipError_t conv_launch_t(ConvArgs a, int variant, float* part, long long 
 // past the partial scratch or select a tile the loader does not support).
 bool conv_choice_ok(const ConvArgs& a, long long part_cap, int v, int ks) {
     const int nvar = (int)(sizeof(kConvVariants) / sizeof(kConvVariants[0]));
+    if (is_k3(v)) {
+        // the tile's own rules, whole chunks for every group of every split, the three staging regions inside the CU's LDS
+        const int bv = conv_tile_variant(v);
+        static const bool off = getenv("WUN_NO_K3") != nullptr && atoi(getenv("WUN_NO_K3")) != 0;
+        if (off || (a.flags & F_PHASE2) || ks < 1 || !conv_choice_ok(a, part_cap, bv, 1)) return false;
+        const ConvVariant& cv = kConvVariants[bv];
+        const int CKC = a.loader == LOADER_DEINT ? cv.CK / 2 : cv.CK;
+        const int Ctot = a.C0 + a.C1;
+        if (Ctot % CKC) return false;
+        const int nchunks = Ctot / CKC;
+        if (nchunks % (WUN_KG * ks) != 0) return false;
+        if (conv_lds_bytes(a, v) > 160 * 1024) return false;
+        const int TT = cv.WT * cv.MT * 16, NT = cv.WN * cv.NW * 16;
+        int bfac;
+        const long long natural = conv_mtiles(a, bv, TT, bfac) * ((a.N + NT - 1) / NT) * bfac;
+        if (natural * ks > 2048) return false;                         // (a launch that fills the chip needs no help)
+        const long long per = (long long)a.B * a.N * ((a.Tout + 3) & ~3);
+        return ks == 1 || (long long)ks * per <= part_cap;
+    }
     if (v >= WUN_FIRST_WIN_VARIANT) return ks == 1 && conv_win_ok(a, v - WUN_FIRST_WIN_VARIANT);     // register-window tiles
     if (v < 0 || v >= nvar || ks < 1) return false;
     const int Ctot = a.C0 + a.C1;
@@ -1383,14 +1465,18 @@ int conv_list_candidates(const ConvArgs& a, long long part_cap, ConvChoice* out,
     static const int ks_menu[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48};
     for (int v = 0; v < nvar && n < maxn; ++v)
         for (unsigned i = 0; i < sizeof(ks_menu) / sizeof(ks_menu[0]) && n < maxn; ++i) {
-            if (!conv_choice_ok(a, part_cap, v, ks_menu[i])) break;  // larger splits fail the same bounds
+            if (!conv_choice_ok(a, part_cap, v, ks_menu[i])) {
+                if (is_k3(v) && ks_menu[i] < 8) continue;            // (divisibility: a larger split may fit again)
+                break;                                               // larger splits fail the same bounds
+            }
             out[n].variant = v; out[n].ksplit = ks_menu[i]; ++n;
         }
     return n;
 }
 
 static_assert(sizeof(kConvVariants) / sizeof(kConvVariants[0]) == WUN_FIRST_WIN_VARIANT, "window variants follow the tile table");
-int conv_num_variants() { return WUN_FIRST_WIN_VARIANT + conv_win_num_variants(); }
+static int first_k3_variant() { return WUN_FIRST_WIN_VARIANT + conv_win_num_variants(); }
+int conv_num_variants() { return first_k3_variant() + kNumK3; }
 
 
 int conv_last_fused_ups() { return t_last_fused_ups; }
@@ -1440,6 +1526,23 @@ hipError_t launch_conv(const ConvArgs& a_in, float* part, long long part_cap, hi
         static const bool win_default = getenv("WUN_CONV_WIN_DEFAULT") == nullptr || atoi(getenv("WUN_CONV_WIN_DEFAULT")) != 0;
         const int wv = win_default ? conv_win_pick(a) : -1;
         if (wv >= 0 && (long long)a.B * ((a.Tout + 255) / 256) * ((a.N + 47) / 48) >= 256) v = WUN_FIRST_WIN_VARIANT + wv;
+    }
+    if (is_k3(v)) {
+        const int bv = conv_tile_variant(v);
+        const bool xv3 = conv_xvec_ok(a, bv);
+#define WUN_K3(i, MT, NW, WT, WN) case i: \
+        if (xv3) return conv_launch_t<MT, NW, WT, WN, 8, true, false, true, WUN_KG>(a, bv, part, part_cap, s); \
+        return conv_launch_t<MT, NW, WT, WN, 8, true, false, false, WUN_KG>(a, bv, part, part_cap, s);
+#define WUN_K3F(i, MT, NW, WT, WN) case i: return conv_launch_t<MT, NW, WT, WN, 8, true, true, false, WUN_KG>(a, bv, part, part_cap, s);
+        switch (bv) {
+            WUN_K3(8, 1, 2, 4, 1) WUN_K3(9, 1, 3, 4, 1) WUN_K3(10, 1, 2, 2, 2) WUN_K3(11, 1, 3, 2, 2)
+            WUN_K3(4, 2, 2, 4, 1) WUN_K3(5, 2, 3, 4, 1)
+            WUN_K3F(34, 1, 2, 4, 1) WUN_K3F(35, 1, 3, 4, 1) WUN_K3F(36, 2, 2, 4, 1) WUN_K3F(37, 2, 3, 4, 1)
+            WUN_K3F(40, 2, 2, 2, 2)
+            default: return hipErrorInvalidValue;
+        }
+#undef WUN_K3
+#undef WUN_K3F
     }
     if (v >= WUN_FIRST_WIN_VARIANT) return launch_conv_win(a, v - WUN_FIRST_WIN_VARIANT, s);
 #ifdef WUN_ABLATION
