@@ -2359,6 +2359,33 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a, long long h0,
 #pragma unroll
             for (int c = 0; c < 2; ++c)
                 acc[s * 2 + c] = (s < a.Sh && c < a.C) ? hw[s * blk + a.Ko * Cin * a.C + c] : 0.f;
+        if (a.Ko == 1 && t - a.padl >= 0 && t - a.padl < a.Tfeat) {
+            // 1-tap head: the feature rows eight at a time, loads first (the generic loop is one dependent load per channel)
+            const int tf = t - a.padl;
+            for (int ci = 0; ci < a.C; ++ci) {
+                const float xv = a.mix_ncw[(long long)b * a.mbs + (long long)ci * a.mpitch + a.moff_feat + tf];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+                        if (s < a.Sh && c < a.C) acc[s * 2 + c] += hw[s * blk + ci * a.C + c] * xv;
+            }
+            const float* __restrict__ fr = a.feat + (long long)b * a.fbs + tf;
+            for (int f0 = 0; f0 < a.F; f0 += 8) {
+                float xf[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xf[j] = f0 + j < a.F ? fr[(long long)(f0 + j) * a.fpitch] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (f0 + j < a.F) {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+#pragma unroll
+                            for (int c = 0; c < 2; ++c)
+                                if (s < a.Sh && c < a.C) acc[s * 2 + c] += hw[s * blk + (a.C + f0 + j) * a.C + c] * xf[j];
+                    }
+            }
+        } else
         for (int k = 0; k < a.Ko; ++k) {
             const int tf = t + k - a.padl;
             if (tf < 0 || tf >= a.Tfeat) continue;
@@ -2450,6 +2477,41 @@ __global__ __launch_bounds__(256) void head_dfeat_kernel(HeadArgs a, long long h
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * 256) {
         const int u = (int)(idx % a.Tfeat), b = (int)(idx / a.Tfeat);
+        if (a.Ko == 1) {
+            // 1-tap head (every shipped config): the Sh * C gradient samples of this position are loaded once, the
+            // feature rows four at a time with all loads issued before the first store (the generic loop below re-reads
+            // the gradient per feature channel and serialises load -> store per channel: 25 us for 27 MB)
+            const int t = u + a.padl;
+            float dp[WUN_MAX_HEAD_ACC];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    dp[s * 2 + c] = (s < a.Sh && c < a.C && t >= 0 && t < a.Tout)
+                        ? a.dpre[(long long)s * a.dps + (long long)b * a.dpbs + (long long)c * a.dppitch + t] : 0.f;
+            const float* __restrict__ fr = a.feat + (long long)b * a.fbs + u;
+            float* __restrict__ dr = a.dzfeat + (long long)b * a.fbs + u;
+            for (int f0 = 0; f0 < a.F; f0 += 4) {
+                float xf[4], g[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xf[j] = f0 + j < a.F ? fr[(long long)(f0 + j) * a.fpitch] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    g[j] = 0.f;
+                    if (f0 + j < a.F) {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+#pragma unroll
+                            for (int c = 0; c < 2; ++c)
+                                if (s < a.Sh && c < a.C) g[j] += hw[s * blk + (a.C + f0 + j) * a.C + c] * dp[s * 2 + c];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (f0 + j < a.F) dr[(long long)(f0 + j) * a.fpitch] = g[j] * ((xf[j] > 0.f) ? 1.f : 0.2f);
+            }
+            continue;
+        }
         for (int f = 0; f < a.F; ++f) {
             float g = 0.f;
             for (int k = 0; k < a.Ko; ++k) {

@@ -145,6 +145,146 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(NarrowWgradArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Streaming form for ONE input channel (the mono audio-input conv: dz is 24 rows of up to 73715 positions, x one row):
+// no LDS, no barrier in the unit loop.  A unit is 256 output positions; lane l of every wave owns positions
+// q0 + 4 l .. + 3, wave w the dz rows [w NPW, (w + 1) NPW).  Per unit a lane loads its dz quads straight from global
+// memory (one 16-byte load per row: a wave instruction reads 1 KiB contiguous) and its x window of 3 SI + KT samples
+// (dword loads at immediate offsets from one address; the four waves read the same window: L1 hits), then 4 KT FMAs per
+// row into KT + 1 accumulators per row.  At the end the 64 lanes of a wave are summed per accumulator with a fixed DPP
+// tree (row_shr 1, 2, 4, 8, then the four row totals in order) and the workgroup writes one partial vector -- the layout
+// narrow_wgrad_reduce_kernel expects.
+template <int KT, int SI, int NPW, bool PF>
+__global__ __launch_bounds__(64 * (24 / NPW)) void narrow_stream_kernel(NarrowWgradArgs a) {
+    constexpr int XWIN = 3 * SI + KT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = wave * NPW;
+
+    float acc[NPW][KT + 1];
+#pragma unroll
+    for (int n = 0; n < NPW; ++n)
+#pragma unroll
+        for (int k = 0; k <= KT; ++k) acc[n][k] = 0.f;
+
+    // row bases of this wave's dz rows (wave-uniform): source s = n / Nper, channel c = n % Nper
+    long long zrow[NPW];
+#pragma unroll
+    for (int n = 0; n < NPW; ++n) {
+        const int nn = n0 + n < a.N ? n0 + n : 0;              // rows past N: loaded, never stored
+        const int sidx = nn / a.Nper, c = nn - sidx * a.Nper;
+        zrow[n] = (long long)sidx * a.zss + (long long)c * a.dzpitch;
+    }
+    const int nunits = a.B * a.nQT;
+    const int u0 = blockIdx.x * a.units_per_split;
+    int u1 = u0 + a.units_per_split;
+    if (u1 > nunits) u1 = nunits;
+    auto load_unit = [&](int u, float (&xv)[XWIN], f32x4 (&z)[NPW]) __attribute__((always_inline)) {
+        const int b = u / a.nQT, qt = u - b * a.nQT;
+        const int q = qt * 256 + 4 * lane;                      // first of this lane's four positions
+        const int t0 = q * SI - a.shift;                        // input sample under tap 0 of position q
+        const float* xr = a.src0 + (long long)b * a.bs0 + a.off0;
+        const float* zb = a.dz + (long long)b * a.dzbs + q;
+        // interior unit (wave-uniform): every sample of every lane inside the row, every position below Tq
+        const int tq_lo = qt * 256 * SI - a.shift, tq_hi = (qt * 256 + 255) * SI - a.shift + KT - 1;
+        const bool interior = tq_lo >= 0 && tq_hi < a.Tin && qt * 256 + 255 < a.Tq && qt * 256 + 255 < a.dzpitch;
+        if (interior) {
+            const float* xp = xr + t0;
+#pragma unroll
+            for (int i = 0; i < XWIN; ++i) xv[i] = xp[i];
+#pragma unroll
+            for (int n = 0; n < NPW; ++n) z[n] = *reinterpret_cast<const f32x4*>(zb + zrow[n]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < XWIN; ++i) {
+                const int t = t0 + i;
+                const int tc = t < 0 ? 0 : (t > a.Tin - 1 ? a.Tin - 1 : t);
+                const float v = xr[tc];
+                xv[i] = (t >= 0 && t < a.Tin) ? v : 0.f;
+            }
+#pragma unroll
+            for (int n = 0; n < NPW; ++n) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qq = q + r < a.Tq ? q + r : a.Tq - 1;
+                    const float v = a.dz[(long long)b * a.dzbs + zrow[n] + qq];
+                    z[n][r] = q + r < a.Tq ? v : 0.f;
+                }
+            }
+        }
+    };
+    // the loads of unit u + 1 are in flight while the FMAs of unit u run (two register sets)
+    float xa[XWIN], xb[XWIN];
+    f32x4 za[NPW], zb2[NPW];
+    if (PF && u0 < u1) load_unit(u0, xa, za);
+    for (int u = u0; u < u1; ++u) {
+        const bool more = PF && u + 1 < u1;
+        if (!PF) load_unit(u, xa, za);
+        if (more) load_unit(u + 1, xb, zb2);
+#pragma unroll
+        for (int n = 0; n < NPW; ++n) {
+#pragma unroll
+            for (int k = 0; k < KT; ++k)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[n][k] = fmaf(xa[r * SI + k], za[n][r], acc[n][k]);
+            acc[n][KT] += (za[n][0] + za[n][1]) + (za[n][2] + za[n][3]);
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < XWIN; ++i) xa[i] = xb[i];
+#pragma unroll
+            for (int n = 0; n < NPW; ++n) za[n] = zb2[n];
+        }
+    }
+    // ---- 64 lanes -> 1 per accumulator: rows of 16 lanes by DPP shifts (lane 15 of a row ends up with the row's sum),
+    // then the four row totals in row order; total j is kept by lane j (two registers: 64 + the rest) ----
+    const int P = (a.KW + 1) * a.N;
+    float* out = a.partial + (long long)(a.split_base + blockIdx.x) * P;
+    float keep0 = 0.f, keep1 = 0.f;
+#pragma unroll
+    for (int n = 0; n < NPW; ++n)
+#pragma unroll
+        for (int k = 0; k <= KT; ++k) {
+            float v = acc[n][k];
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xF, 0xF, false));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xF, 0xF, false));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xF, 0xF, false));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xF, 0xF, false));
+            const int vi = __builtin_bit_cast(int, v);
+            const float tot = ((__builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 15)) +
+                                __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 31))) +
+                               __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 47))) +
+                              __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 63));
+            constexpr int dummy = 0; (void)dummy;
+            const int j = n * (KT + 1) + k;
+            if (j < 64) keep0 = lane == j ? tot : keep0;
+            else keep1 = lane == j - 64 ? tot : keep1;
+        }
+    // lane j holds accumulator j = n * (KT + 1) + k of this wave: weights out[k * N + n0 + n] (k < KW), bias out[KW * N + n0 + n]
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int j = lane + 64 * h;
+        if (j < NPW * (KT + 1)) {
+            const int n = j / (KT + 1), k = j - n * (KT + 1);
+            const float v = h ? keep1 : keep0;
+            if (n0 + n < a.N) {
+                if (k < a.KW) out[k * a.N + n0 + n] = v;
+                else if (k == KT) out[a.KW * a.N + n0 + n] = v;
+            }
+        }
+    }
+}
+
+#ifndef WUN_NS_NPW
+#define WUN_NS_NPW 4      /* dz rows per wave (24 / NPW waves per workgroup); measured 3 / 4 / 6: 42.9 / 36.8 / 37.5 us on the stride-2 part */
+#define WUN_NS_PF false  /* two register sets (loads of the next unit during the FMAs) */
+#endif
+// shapes the streaming form serves: one input channel, all rows on four waves of NPW = 6, taps <= 15
+static bool narrow_stream_ok(const NarrowWgradArgs& a) {
+    static const bool off = getenv("WUN_NO_NARROW_STREAM") != nullptr && atoi(getenv("WUN_NO_NARROW_STREAM")) != 0;
+    return !off && a.C0 + a.C1 == 1 && a.N <= 24 && a.KW >= 4 && a.KW <= 15;
+}
+
 // out element (k, ci, n = s*Nper + c) -> source s: weights [K][Ctot][Nper] at woff[s], bias at boff[s].
 // One workgroup per output element: 256 threads sum the splits (thread t takes splits t, t+256, ...), then a
 // fixed-order tree through LDS -- deterministic, and ~nsplit/256 dependent loads per thread instead of nsplit.
@@ -199,7 +339,9 @@ long long narrow_wgrad_partial_floats(const NarrowWgradArgs& a) { return (long l
 
 int narrow_wgrad_pick_nsplit(const NarrowWgradArgs& a) {
     const int units = narrow_wgrad_units(a);
-    int cap = 1024;                                         // ~4 workgroups per CU, each streaming >= 1 unit
+    // ~4 workgroups per CU, each streaming >= 1 unit; the streaming form pays a 64-lane reduction of every accumulator
+    // per workgroup: one workgroup per CU, >= 4 units each (measured 256 / 512 / 1024: 36.8 / 44.6 / 51.3 us)
+    int cap = narrow_stream_ok(a) ? 256 : 1024;
     if (const char* e = getenv("WUN_NARROW_SPLITS")) cap = atoi(e);
     int ns = units < cap ? units : cap;
     return ns < 1 ? 1 : ns;
@@ -211,6 +353,16 @@ hipError_t launch_narrow_wgrad(NarrowWgradArgs a, hipStream_t s) {
     a.nQT = (a.Tq + WUN_NW_TQ - 1) / WUN_NW_TQ;
     const int units = a.B * a.nQT;
     a.units_per_split = (units + a.nsplit - 1) / a.nsplit;
+    if (narrow_stream_ok(a)) {
+        char tag[160];
+        snprintf(tag, sizeof(tag), "C=1 N=%d T=%d K=%d stride=%d B=%d nsplit=%d stream", a.N, a.Tq, a.KW, a.stride, a.B, a.nsplit);
+        prof_scope_begin("narrow_wgrad_kernel", 2.0 * a.KW * (double)a.N * (double)a.Tq * a.B, s, tag,
+                         4.0 * (double)a.B * a.Tq * ((double)a.N + (double)a.stride));
+        if (a.stride == 2) hipLaunchKernelGGL((narrow_stream_kernel<15, 2, WUN_NS_NPW, WUN_NS_PF>), dim3((unsigned)a.nsplit), dim3(64 * (24 / WUN_NS_NPW)), 0, s, a);
+        else hipLaunchKernelGGL((narrow_stream_kernel<15, 1, WUN_NS_NPW, WUN_NS_PF>), dim3((unsigned)a.nsplit), dim3(64 * (24 / WUN_NS_NPW)), 0, s, a);
+        prof_scope_end(s);
+        return hipGetLastError();
+    }
     const size_t lds = narrow_wgrad_lds(a);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const int KT = narrow_kt(a.KW);
