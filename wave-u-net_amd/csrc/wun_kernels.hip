@@ -1621,7 +1621,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a, int nMG
     const int li = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef WUN_ABLATION
-    const bool tr_on = (a.ablate & 64) && tid == 0 && blockIdx.x < WUN_TRACE_WGS;      // workgroup trace, tools/diag_r3g.py
+    const bool tr_on = (a.ablate & 64) && tid == 0 && blockIdx.x < WUN_TRACE_WGS;      // workgroup trace (diagnostic builds)
     unsigned long long* trp = g_wun_trace + (size_t)(blockIdx.x < WUN_TRACE_WGS ? blockIdx.x : 0) * 16;
     if (tr_on) {
         trp[0] = __builtin_readcyclecounter();
