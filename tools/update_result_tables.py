@@ -41,9 +41,9 @@ def main():
     s = open(p).read()
     i = s.index("## 4. Results")
     r = []
-    r.append("| **M1 + context (configs[1], the bench line)**, 147 443 → 16 389 | 1 | fp32 | **%.3g** | **%.2f** | executed FLOPs (dead odd outputs skipped, SURVEY §8d) %.1f TFLOP/s = %.0f %% of 157.3 (the reference graph's skipped FLOPs are NOT counted as achieved); kernel family `conv_mfma_kernel` %.3f, `wgrad_mfma_kernel` %.3f by HIP events net of the event pair's own %.2f µs (conv %.3f uncorrected; DESIGN §6) | %.3g (%d cores, %s; whole batch) / %.3g (1 thread) | %.0f× |" % (
+    r.append("| **M1 + context (configs[1], the bench line)**, 147 443 → 16 389 | 1 | fp32 | **%.3g** | **%.2f** | executed FLOPs (dead odd outputs skipped, SURVEY §8d) %.1f TFLOP/s = %.0f %% of 157.3 (the reference graph's skipped FLOPs are NOT counted as achieved); kernel families `conv_mfma_kernel` %.3f, `wgrad_win_kernel` %.3f, `wgrad_mfma_kernel` (deep levels) %.3f by HIP events net of the event pair's own %.2f µs (conv %.3f uncorrected; DESIGN §6) | %.3g (%d cores, %s; whole batch) / %.3g (1 thread) | %.0f× |" % (
         b["value"], b["ms_per_step"], tf(b), 100 * tf(b) / 157.3, b["roofline"]["family_frac"]["conv_mfma_kernel"],
-        b["roofline"]["family_frac"]["wgrad_mfma_kernel"], b["roofline"].get("event_bracket_overhead_us", 0.0),
+        b["roofline"]["family_frac"].get("wgrad_win_kernel", float("nan")), b["roofline"]["family_frac"]["wgrad_mfma_kernel"], b["roofline"].get("event_bracket_overhead_us", 0.0),
         b["roofline"].get("achieved_raw_events", b["roofline"]["achieved"]) / 157.3, cb["value"], cb["cores"], cb["cpu_model"], cb["value_1_thread"], b["value"] / cb["value"]))
     r.append("| same | 1 | bf16 mode | %.3g | %.2f | — | — | — |" % (cfg["m1_context_bf16"]["value"], cfg["m1_context_bf16"]["ms_per_step"]))
     r.append("| M1 as shipped (same padding, configs[0]), T=16 384 | 1 | fp32 | %.3g | %.2f | %.0f %% of 1.76e8 (%.1f TFLOP/s) | — | — |" % (
@@ -68,8 +68,8 @@ def main():
            "| Config | GPUs | dtype | samples/s (out) | ms/step | fraction of the binding roofline | CPU baseline samples/s | speed-up |\n"
            "|---|---|---|---|---|---|---|---|\n" + "\n".join(r) + "\n\n"
            "Multi-GPU rows are measured by the driver (`SCALE_rNN.json`); none was measured so far (no multi-GPU node was available in\n"
-           "rounds 1-3; `python bench.py --gpus N` now launches itself).  Earlier rounds, same rows: round 1 2.77e7 / 9.47 ms (M1 + context),\n"
-           "6.82e7 / 3.85 ms (M1), 327 ms (deep); round 2 2.91e7 / 9.00 ms, 7.14e7 / 3.67 ms, 318 ms.\n"
+           "rounds 1-4; `python bench.py --gpus N` launches itself).  Earlier rounds, same rows: round 1 2.77e7 / 9.47 ms (M1 + context),\n"
+           "6.82e7 / 3.85 ms (M1), 327 ms (deep); round 2 2.91e7 / 9.00 ms, 7.14e7 / 3.67 ms, 318 ms; round 3 3.10e7 / 8.46 ms (8.53 on the driver's box), 7.59e7 / 3.45 ms, 298 ms.\n"
            "(`tools/update_result_tables.py` regenerates this section and DESIGN.md's table from `profiles/`.)\n")
     open(p, "w").write(s[:i] + new)
     print("\n".join(rows))
