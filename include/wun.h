@@ -230,6 +230,12 @@ int wun_op_set_wgrad_bf16(int on);
  * bf16 hook is on. */
 int wun_op_set_wgrad_win(int on);
 
+/* Test hook: run the following wun_op_conv1d_wgrad calls on the direct-reduction ("narrow") kernels the plan uses for the
+ * layers without a dense channel x channel face -- the 1-/2-channel audio-input conv and the output head (wun_narrow.hip:
+ * the LDS-staged form for Cin * Cout <= 256, the streaming form for one input channel and <= 24 output channels).  Other
+ * shapes fail with WUN_ERR_UNSUPPORTED. */
+int wun_op_set_wgrad_narrow(int on);
+
 /* The bf16 speed mode's conv as a single operator (wun_op_conv1d semantics, Cin >= 8, K <= 15): operands
  * are rounded to bf16 (nearest-even), products accumulate in fp32.  scratch: device floats, at least
  * wun_op_conv1d_bf16_scratch(cin, cout, k) (packed bf16 weight image).  Synchronises the stream. */

@@ -472,3 +472,49 @@ def test_window_wgrad_refuses_what_it_does_not_serve(lib):
             assert rc == -2, (Cin, K, rc)
     finally:
         lib.wun_op_set_wgrad_win(0)
+
+
+# ---- the direct-reduction weight gradients of the narrow layers (wun_narrow.hip) as single operators ----
+NARROW_CASES = [
+    # (B, Cin, Cout, K, T, stride, pad_left, same)
+    (3, 1, 24, 15, 5000, 2, 0, False),          # mono audio-input conv, decimated positions: streaming form, ragged last unit
+    (3, 1, 24, 15, 1303, 1, 0, False),          # ... its skip-window positions
+    (2, 1, 24, 15, 777, 1, 7, True),            # same padding: zero samples on both sides
+    (2, 1, 20, 9, 600, 1, 0, False),            # fewer rows than the waves hold, taps < 15
+    (2, 2, 24, 15, 900, 2, 0, False),           # stereo input: the LDS-staged form
+    (2, 25, 2, 1, 1000, 1, 0, False),           # the output head's shape (25 feature channels -> 2 samples)
+    (2, 26, 4, 3, 500, 1, 1, True),
+]
+
+
+@pytest.mark.parametrize("case", NARROW_CASES, ids=[str(c) for c in NARROW_CASES])
+def test_narrow_wgrad_operator(lib, case):
+    B, Cin, Cout, K, T, stride, pad, same = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31) + 17)
+    x = rng.uniform(-1, 1, (B, Cin, T)).astype(np.float32)
+    t_out = _t_out(T, K, stride, same)
+    dz = rng.uniform(-1, 1, (B, Cout, t_out)).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64)
+    wtn = torch.zeros((K, Cin, Cout), dtype=torch.float64, requires_grad=True)
+    need = (t_out - 1) * stride + K - pad
+    xp = F.pad(xt, (pad, max(0, need - T)))
+    y = F.conv1d(xp, wtn.permute(2, 1, 0), None, stride=stride)[:, :, :t_out]
+    (y * torch.tensor(dz, dtype=torch.float64)).sum().backward()
+    ref_dw = wtn.grad.numpy()
+    ref_db = dz.astype(np.float64).sum(axis=(0, 2))
+    sw, sb = max(1.0, np.abs(ref_dw).max()), max(1.0, np.abs(ref_db).max())
+    dxg, dzg = _cuda(x), _cuda(dz)
+    _lib.check(lib.wun_op_set_wgrad_narrow(1))
+    try:
+        scr = torch.empty(int(lib.wun_op_conv1d_wgrad_scratch(B, Cin, Cout, K, t_out)) + (1 << 20), device="cuda")
+        gdw = torch.full((K, Cin, Cout), float("nan"), device="cuda")
+        gdb = torch.full((Cout,), float("nan"), device="cuda")
+        _lib.check(lib.wun_op_conv1d_wgrad(dxg.data_ptr(), dzg.data_ptr(), gdw.data_ptr(), gdb.data_ptr(), scr.data_ptr(),
+                                           B, Cin, Cout, K, T, t_out, stride, pad, _stream()))
+        torch.cuda.synchronize()
+    finally:
+        lib.wun_op_set_wgrad_narrow(0)
+    ew = np.abs(gdw.cpu().numpy() - ref_dw).max() / sw
+    eb = np.abs(gdb.cpu().numpy() - ref_db).max() / sb
+    record("narrow_wgrad_operator", str(case), max(ew, eb), OP_TOL)
+    assert ew <= OP_TOL and eb <= OP_TOL, (ew, eb)

@@ -58,6 +58,7 @@ _SIGS = {
     "wun_op_force_wgrad_variant": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "wun_op_set_wgrad_bf16": (C.c_int, [C.c_int]),
     "wun_op_set_wgrad_win": (C.c_int, [C.c_int]),
+    "wun_op_set_wgrad_narrow": (C.c_int, [C.c_int]),
     "wun_op_conv1d_ex": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, _P, _P] + [C.c_int] * 12 + [_P]),
     "wun_profile_begin": (C.c_int, []),
     "wun_profile_end": (C.c_int, [C.c_char_p, C.c_int64]),

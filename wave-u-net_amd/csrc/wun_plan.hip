@@ -1632,6 +1632,7 @@ static const long long kOpScratchFloats = 8ll << 20;
 static int g_op_variant = -1, g_op_ksplit = 0;          // wun_op_force_conv_variant (test hook)
 static int g_op_wg_mtw = 0, g_op_wg_nw = 0, g_op_wg_nsplit = 0;   // wun_op_force_wgrad_variant (test hook)
 static int g_op_wg_bf16 = 0;                                       // wun_op_set_wgrad_bf16 (test hook)
+static int g_op_wg_narrow = 0;                                     // wun_op_set_wgrad_narrow (test hook)
 static int g_op_wg_win = 0;                                        // wun_op_set_wgrad_win (test hook)
 static float* op_scratch() {
     static float* buf = nullptr;
@@ -1739,6 +1740,23 @@ extern "C" int wun_op_conv1d_wgrad(const float* x, const float* dz, float* dw, f
                              hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpy2DAsync(zs, (size_t)zp * 4, dz, (size_t)t_out * 4, (size_t)t_out * 4, (size_t)batch * cout,
                              hipMemcpyDeviceToDevice, s));
+    if (g_op_wg_narrow) {
+        // the direct-reduction kernels of wun_narrow.hip (what the plan runs for the audio-input conv and the head)
+        NarrowWgradArgs nw;
+        memset(&nw, 0, sizeof(nw));
+        nw.src0 = xs; nw.bs0 = (long long)cin * xp; nw.pitch0 = xp; nw.off0 = 0; nw.C0 = cin;
+        nw.Tin = t_in; nw.shift = pad_left; nw.KW = k; nw.stride = stride;
+        nw.dz = zs; nw.zss = 0; nw.dzbs = (long long)cout * zp; nw.dzpitch = zp;
+        nw.N = nw.Nper = cout; nw.Tq = t_out; nw.B = batch;
+        if (!narrow_wgrad_supported(nw)) return fail(WUN_ERR_UNSUPPORTED, "shape not served by the narrow weight-gradient kernels");
+        nw.nsplit = narrow_wgrad_pick_nsplit(nw);
+        part = (float*)(((uintptr_t)part + 255) & ~(uintptr_t)255);
+        nw.partial = part; nw.split_base = 0;
+        HIP_TRY(launch_narrow_wgrad(nw, s));
+        const long long woff[4] = {0, 0, 0, 0}, boff[4] = {(long long)(db - dw), 0, 0, 0};
+        HIP_TRY(launch_narrow_wgrad_reduce(nw, part, nw.nsplit, dw, woff, boff, s));
+        return WUN_OK;
+    }
     WgradArgs w = op_wgrad_args(xs, zs, batch, cin, cout, k, t_in, t_out, stride, pad_left, xp, zp);
     if (g_op_wg_bf16 && !wgrad_bf16_supported(w)) return fail(WUN_ERR_UNSUPPORTED, "shape not served by the bf16 weight-gradient kernel");
     w.bf16 = g_op_wg_bf16;
@@ -1824,6 +1842,7 @@ extern "C" int wun_op_num_conv_variants(void) { return conv_num_variants(); }
 
 extern "C" int wun_op_set_wgrad_bf16(int on) { g_op_wg_bf16 = on ? 1 : 0; return WUN_OK; }
 extern "C" int wun_op_set_wgrad_win(int on) { g_op_wg_win = on ? 1 : 0; return WUN_OK; }
+extern "C" int wun_op_set_wgrad_narrow(int on) { g_op_wg_narrow = on ? 1 : 0; return WUN_OK; }
 
 extern "C" int wun_op_force_wgrad_variant(int mtw, int nw, int nsplit) {
     g_op_wg_mtw = mtw; g_op_wg_nw = nw; g_op_wg_nsplit = nsplit;
