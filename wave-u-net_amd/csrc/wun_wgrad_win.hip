@@ -582,6 +582,7 @@ bool wgrad_win_supported(const WgradArgs& a) {
     if (a.KW == 15 && (Ctot % 8) != 0) return false;               // row tiles of 8 channels x 2 tap groups
     if (a.C1 > 0 && (a.C0 % (a.KW == 15 ? 8 : 1)) != 0) return false;
     if ((long long)Ctot * std::max(a.pitch0, a.pitch1) >= (1ll << 30)) return false;   // 30-bit element offsets
+    if ((long long)a.N * a.dzpitch >= (1ll << 30)) return false;                        // ... of the dz rows of one excerpt too
     return true;
 }
 
