@@ -1003,22 +1003,16 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvArgs a, i
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         const float* pp = a.part + bn * TP + q;
         // the loads of a batch are all in flight before the first add (a load + wait per split made this kernel
-        // ksplit memory latencies long: 12-16 us on the critical path of every deep level); the sum order is unchanged
+        // ksplit memory latencies long: 12-16 us on the critical path of every deep level); the sum order is unchanged.
+        // Batches of FOUR: this kernel runs 46 times per step beside the MFMA kernels and has to find room in their
+        // register files -- batches of 8 (92 VGPRs) 8.41 ms per step, of 4 (69 VGPRs) 8.39, one batch of 16 (~130) 8.56
         int ks = 0;
-        for (; ks + 8 <= ksplit; ks += 8) {
-            f32x4 t[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = *reinterpret_cast<const f32x4*>(pp + (long long)(ks + j) * sstride);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v += t[j];
-        }
-        if (ks + 4 <= ksplit) {
+        for (; ks + 4 <= ksplit; ks += 4) {
             f32x4 t[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) t[j] = *reinterpret_cast<const f32x4*>(pp + (long long)(ks + j) * sstride);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v += t[j];
-            ks += 4;
         }
         {
             f32x4 t[3];
