@@ -1,8 +1,10 @@
 // Probe: what does a cross-stream dependency cost the stream that SIGNALS it?  A chain of N short kernels on stream A,
 // with after each kernel (a) nothing, (b) hipEventRecord (+ hipStreamWaitEvent on stream B), (c) hipStreamWriteValue32
-// (+ hipStreamWaitValue32 on B), (d) a 1-thread flag kernel (+ hipStreamWaitValue32 on B).
+// (+ hipStreamWaitValue32 on B), (d) a 1-thread flag kernel (+ hipStreamWaitValue32 on B), (e) round 4: the event attached to
+// the kernel dispatch itself (hipExtLaunchKernelGGL's stopEvent: no packet of its own) (+ hipStreamWaitEvent on B).
 // build: hipcc -O3 --offload-arch=gfx950 tools/sync_cost_probe.hip -o /tmp/sync_probe
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdio>
 #include <vector>
 __global__ void work(float* x) { float v = x[threadIdx.x]; for (int i = 0; i < 2000; ++i) v = v * 1.0001f + 0.5f; x[threadIdx.x] = v; }
@@ -21,12 +23,17 @@ int main() {
     else CK(hipMemset(flag, 0, 8));
     hipEvent_t t0, t1; CK(hipEventCreate(&t0)); CK(hipEventCreate(&t1));
     unsigned epoch = 0;
-    for (int mode = 0; mode < 4; ++mode) {
-        if (mode >= 2 && !flag) continue;
+    for (int mode = 0; mode < 5; ++mode) {
+        if ((mode == 2 || mode == 3) && !flag) continue;
         for (int rep = 0; rep < 3; ++rep) {
             CK(hipDeviceSynchronize());
             CK(hipEventRecord(t0, sa));
             for (int i = 0; i < N; ++i) {
+                if (mode == 4) {
+                    hipExtLaunchKernelGGL(work, dim3(64), dim3(256), 0, sa, nullptr, ev[i], 0, a);
+                    CK(hipStreamWaitEvent(sb, ev[i], 0)); side<<<1, 64, 0, sb>>>(b);
+                    continue;
+                }
                 work<<<64, 256, 0, sa>>>(a);
                 if (mode == 1) { CK(hipEventRecord(ev[i], sa)); CK(hipStreamWaitEvent(sb, ev[i], 0)); side<<<1, 64, 0, sb>>>(b); }
                 if (mode == 2) { ++epoch; CK(hipStreamWriteValue32(sa, flag, epoch, 0)); CK(hipStreamWaitValue32(sb, flag, epoch, hipStreamWaitValueGte, 0xFFFFFFFFu)); side<<<1, 64, 0, sb>>>(b); }
@@ -36,7 +43,7 @@ int main() {
             CK(hipDeviceSynchronize());
             float ms; CK(hipEventElapsedTime(&ms, t0, t1));
             if (rep == 2) printf("mode %d (%s): %.2f us per kernel on the signalling stream\n", mode,
-                                 mode == 0 ? "no sync" : mode == 1 ? "event record" : mode == 2 ? "hipStreamWriteValue32" : "flag kernel", 1e3 * ms / N);
+                                 mode == 0 ? "no sync" : mode == 1 ? "event record" : mode == 2 ? "hipStreamWriteValue32" : mode == 3 ? "flag kernel" : "stop event on the dispatch (hipExtLaunchKernelGGL)", 1e3 * ms / N);
         }
     }
     return 0;
