@@ -74,6 +74,11 @@ GOLDEN_CASES = {
     "filter1_context_small": dict(cfg=dict(_SMALL, output_type="difference", context=True, filter_size=1,
                                            input_filter_size=1, merge_filter_size=3, mono_downmix=False),
                                   batch=2, frames=40, seed=23, training=True),
+    # baseline_comparison (Config.py:123-134) at reduced depth: 34 initial filters -- layer widths 34, 68, 102, 136 are
+    # NOT multiples of 8, so the register-window weight gradient and the DMA-staged conv tiles do not apply and the
+    # LDS-tiled fall-back kernels carry the whole network
+    "baseline_comparison_small": dict(cfg=dict(num_layers=3, num_initial_filters=34, output_type="difference",
+                                               context=True), batch=2, frames=40, seed=24, training=True),
     # full-size M1 (Config.py:15-33), one excerpt
     "M1_full": dict(cfg=dict(), batch=1, frames=16384, seed=31, training=True),
     # full-size M1 architecture with context (BASELINE.json configs[1] shape), one excerpt

@@ -124,6 +124,61 @@ def test_named_configs_present():
     assert wun.get_config("full_multi_instrument")["source_names"] == ["bass", "drums", "other", "vocals"]
 
 
+# Literal transcription of the reference's sacred named configs (/root/reference/Config.py:52-134; the spectrogram
+# U-Net ones, :136-161, are out of scope) and of its base dict (:9-39, minus the site paths of :9-11).
+_REF_BASE = {
+    "model_base_dir": "checkpoints", "log_dir": "logs", "batch_size": 16, "init_sup_sep_lr": 1e-4,
+    "epoch_it": 2000, "cache_size": 4000, "num_workers": 4, "num_snippets_per_track": 100,
+    "num_layers": 12, "filter_size": 15, "merge_filter_size": 5, "input_filter_size": 15,
+    "output_filter_size": 1, "num_initial_filters": 24, "num_frames": 16384, "expected_sr": 22050,
+    "mono_downmix": True, "output_type": "direct", "output_activation": "tanh", "context": False,
+    "network": "unet", "upsampling": "linear", "task": "voice", "augmentation": True,
+    "raw_audio_loss": True, "worse_epochs": 20,
+}
+_REF_NAMED = {
+    "baseline": {},                                                                              # :52-54
+    "baseline_diff": {"output_type": "difference"},                                              # :56-61
+    "baseline_context": {"output_type": "difference", "context": True},                          # :63-69
+    "baseline_stereo": {"output_type": "difference", "context": True, "mono_downmix": False},    # :71-78
+    "full": {"output_type": "difference", "context": True, "upsampling": "learned",
+             "mono_downmix": False},                                                             # :80-88
+    "full_44KHz": {"output_type": "difference", "context": True, "upsampling": "learned",
+                   "mono_downmix": False, "expected_sr": 44100},                                 # :90-99
+    "baseline_context_smallfilter_deep": {"output_type": "difference", "context": True, "num_layers": 14,
+                                          "duration": 7, "filter_size": 5, "merge_filter_size": 1},   # :101-110
+    "full_multi_instrument": {"output_type": "difference", "context": True, "upsampling": "linear",
+                              "mono_downmix": False, "task": "multi_instrument"},                # :112-121
+    "baseline_comparison": {"batch_size": 4, "output_type": "difference", "context": True,
+                            "num_frames": 768 * 127 + 1024, "duration": 13, "expected_sr": 8192,
+                            "num_initial_filters": 34},                                          # :123-134
+}
+
+
+def test_named_configs_equal_the_reference_dicts():
+    """Every reference named config resolves to the reference's model_config, key by key (a dropped override trains
+    a different network without any error: round 4's `baseline_comparison` lacked expected_sr / num_initial_filters)."""
+    from wave_u_net_amd import config as C
+    assert C.BASE_MODEL_CONFIG == _REF_BASE
+    for name, over in _REF_NAMED.items():
+        assert C.NAMED_CONFIGS[name] == over, name
+        want = dict(_REF_BASE)
+        want.update(over)
+        multi = want["task"] == "multi_instrument"                                               # Config.py:43-50
+        want["source_names"] = ["bass", "drums", "other", "vocals"] if multi else ["accompaniment", "vocals"]
+        want["num_sources"] = len(want["source_names"])
+        want["num_channels"] = 1 if want["mono_downmix"] else 2
+        assert wun.get_config(name) == want, name
+    cmp_ = wun.get_config("baseline_comparison")
+    assert cmp_["num_initial_filters"] == 34 and cmp_["expected_sr"] == 8192 and cmp_["num_frames"] == 98560
+    # its plan is the 34-filter network (13.7 M parameters at 12 levels), not the 24-filter one
+    sep = UnetAudioSeparator(cmp_)
+    (tin, _), (tout, _) = [(s[1], s[2]) for s in sep.get_padding(np.array([4, cmp_["num_frames"], 0]))]
+    plan = sep._plan(1, int(tin))
+    assert plan.info.num_params == sum(
+        15 * ci * co + co for ci, co in zip([1] + [34 * i for i in range(1, 13)], [34 * i for i in range(1, 14)])
+    ) + sum(5 * (34 * (12 - j) + 34 * (13 - j)) * 34 * (12 - j) + 34 * (12 - j) for j in range(12)) + 1 * (1 + 34) * 1 + 1
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "wave-u-net_amd")
     for fn in os.listdir(pkg):

@@ -278,7 +278,8 @@ def test_forward_matches_reference_goldens(lib, name, golden_dir):
 
 STEP_CASES = ["baseline_small", "baseline_diff_small", "baseline_context_small", "baseline_stereo_small",
               "full_small", "full_multi_small", "learned_same_small", "odd_filters_small",
-              "odd_filters_same_small", "input_filter_mismatch_small", "filter1_context_small"]
+              "odd_filters_same_small", "input_filter_mismatch_small", "filter1_context_small",
+              "baseline_comparison_small"]
 
 
 def _grad_check(sep, tp, ograds, tol=GRAD_TOL, tag="?"):

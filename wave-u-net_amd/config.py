@@ -47,7 +47,8 @@ NAMED_CONFIGS = {                # Config.py:52-161 (the Wave-U-Net ones)
                               "upsampling": "linear", "mono_downmix": False,
                               "task": "multi_instrument"},
     "baseline_comparison": {"batch_size": 4, "output_type": "difference", "context": True,
-                            "num_frames": 768 * 127 + 1024, "duration": 13},
+                            "num_frames": 768 * 127 + 1024, "duration": 13,
+                            "expected_sr": 8192, "num_initial_filters": 34},   # Config.py:123-134
     # BASELINE.json configs[1]: the M1 architecture run with input context (~147k samples in)
     "m1_context": {"context": True},
     # BASELINE.json configs[4]: 16 levels / 48 base channels, stereo, 4 sources, same padding,
