@@ -115,6 +115,25 @@ void wun_plan_destroy(wun_plan* plan);
 int wun_plan_query(const wun_plan* plan, wun_plan_info* info);
 int wun_plan_tensor(const wun_plan* plan, int64_t index, wun_tensor_info* info);
 
+/* Where the forward activations of the plan live in the caller's workspace after wun_forward(training = 1) -- what
+ * the backward pass reads its LeakyReLU derivatives from (Utils.py:79-80).  Used by the parity tests to pin the float64
+ * oracle's LeakyReLU branch decisions to the ones the kernels took (a pre-activation within fp32 rounding of 0 otherwise
+ * decides a 1-vs-0.2 factor differently in the two precisions), and by tools/ws_diff.py.  Every tensor is NCW:
+ * element (b, c, j) at workspace[offset + b*batch_stride + c*pitch + j] and holds the POST-activation output of conv
+ * position t0 + j*tstep of its layer (UnetAudioSeparator.py:98-100,102,123):
+ *   kind 0, index i : decimated stream of down level i  (t0 = 0, tstep = 2: the [:, ::2, :] of :100)
+ *   kind 1, index i : skip window of down level i       (context: the centre crop Utils.crop takes, t0 = crop start;
+ *                                                         same padding: the whole conv output)
+ *   kind 2          : bottleneck conv output (:102)
+ *   kind 3, index j : output of up conv j (:123)
+ * All fields are int64.  WUN_ERR_INVALID for an unknown kind / index. */
+typedef struct wun_activation_info {
+    int64_t offset, batch_stride, pitch;    /* in floats */
+    int64_t channels, frames;               /* frames = valid positions j per row */
+    int64_t t0, tstep;
+} wun_activation_info;
+int wun_plan_activation(const wun_plan* plan, int32_t kind, int32_t index, wun_activation_info* info);
+
 /* get_output (UnetAudioSeparator.py:85-144).
  *   params   : device, arena_floats
  *   mix_btc  : device, [B, Tin, C]

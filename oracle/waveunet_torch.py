@@ -76,9 +76,32 @@ class _TfLeakyReLU(torch.autograd.Function):
         return g * torch.where(0.2 * x >= x, torch.full_like(x, 0.2), torch.ones_like(x))
 
 
-def leaky_relu(x):
-    """Utils.LeakyReLU, Utils.py:79-80: max(0.2*x, x); gradient 0.2 at x == 0 as in TensorFlow."""
-    return _TfLeakyReLU.apply(x)
+class _PinnedLeakyReLU(torch.autograd.Function):
+    """LeakyReLU whose branch is PRESCRIBED: y = x where `pos`, 0.2 x elsewhere; dy/dx = 1 / 0.2 accordingly.  Identical
+    to _TfLeakyReLU wherever pos == (x > 0).  Used by the parity tests to evaluate the float64 oracle on the branch
+    decisions the fp32 kernels took: a pre-activation within fp32 rounding of 0 (|x| ~ 1e-8) can fall on either side of
+    0 in the two precisions, and that one 1-vs-0.2 factor moves every gradient upstream by up to a few 1e-4 of max|g|
+     -- with the branches pinned the comparison measures the arithmetic alone.  The forward values
+    differ from the free oracle's by at most 0.8 |x| at the flipped elements, i.e. by fp32 rounding."""
+
+    @staticmethod
+    def forward(ctx, x, pos):
+        ctx.save_for_backward(pos)
+        return torch.where(pos, x, 0.2 * x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (pos,) = ctx.saved_tensors
+        return g * torch.where(pos, torch.ones_like(g), torch.full_like(g, 0.2)), None
+
+
+def leaky_relu(x, pin=None):
+    """Utils.LeakyReLU, Utils.py:79-80: max(0.2*x, x); gradient 0.2 at x == 0 as in TensorFlow.
+    pin = (pos, known) bool tensors of x's shape: where `known`, the branch is taken from `pos` instead of from x."""
+    if pin is None:
+        return _TfLeakyReLU.apply(x)
+    pos, known = pin
+    return _PinnedLeakyReLU.apply(x, torch.where(known, pos, x > 0))
 
 
 def conv1d_tf(x, kernel, bias, same):
@@ -145,11 +168,13 @@ def audio_clip(x, training):
 # ---------------------------------------------------------------------------
 # forward / loss / optimizer
 # ---------------------------------------------------------------------------
-def get_output(cfg, tparams, mix_btc, training, return_intermediates=False):
+def get_output(cfg, tparams, mix_btc, training, return_intermediates=False, pins=None):
     """UnetAudioSeparator.get_output, UnetAudioSeparator.py:85-144.
 
     mix_btc: torch [B, T, C]; tparams: list of (name, tensor) in TF creation order.
-    Returns dict source_name -> [B, Tout, C]."""
+    Returns dict source_name -> [B, Tout, C].
+    pins: optional {"down<i>" | "down<i>/dec" | "bottleneck" | "up<i>": (pos, known)} -- prescribed LeakyReLU branches
+    (leaky_relu); "down<i>/dec" pins the copy of down level i's output that the decimation reads separately."""
     cfg = shapes.finalize_config(cfg)
     L = cfg["num_layers"]
     same = not cfg["context"]
@@ -158,18 +183,26 @@ def get_output(cfg, tparams, mix_btc, training, return_intermediates=False):
     def nxt():
         return next(it)[1]
 
+    def pin(name):
+        return None if pins is None else pins.get(name)
+
     x_in = mix_btc.permute(0, 2, 1)           # NCW
     cur = x_in
     enc = []
     inter = {}
     for i in range(L):                         # :97-100
         k, b = nxt(), nxt()
-        cur = leaky_relu(conv1d_tf(cur, k, b, same))
+        pre = conv1d_tf(cur, k, b, same)
+        cur = leaky_relu(pre, pin("down%d" % i))
         enc.append(cur)
         inter["down%d" % i] = cur
+        if pin("down%d/dec" % i) is not None:
+            # the decimated stream pinned separately from the skip tensor (two kernel launches with different
+            # summation orders produce them; tests/test_gpu_parity.py:_gpu_pins)
+            cur = leaky_relu(pre, pin("down%d/dec" % i))
         cur = cur[:, :, ::2]
     k, b = nxt(), nxt()                        # :102
-    cur = leaky_relu(conv1d_tf(cur, k, b, same))
+    cur = leaky_relu(conv1d_tf(cur, k, b, same), pin("bottleneck"))
     inter["bottleneck"] = cur
     for i in range(L):                         # :107-125
         if cfg["upsampling"] == "learned":
@@ -180,7 +213,7 @@ def get_output(cfg, tparams, mix_btc, training, return_intermediates=False):
         assert skip.shape[2] == cur.shape[2] or cfg["context"]          # :121
         cur = torch.cat([crop(skip, cur.shape[2]), cur], dim=1)        # Utils.py:23-24
         k, b = nxt(), nxt()
-        cur = leaky_relu(conv1d_tf(cur, k, b, same))
+        cur = leaky_relu(conv1d_tf(cur, k, b, same), pin("up%d" % i))
         inter["up%d" % i] = cur
     feat = torch.cat([crop(x_in, cur.shape[2]), cur], dim=1)            # :127
 
@@ -279,13 +312,14 @@ def synthetic_batch(cfg, batch, t_in, t_out, seed=1337):
 
 
 def chunked_train_step(cfg, named_params, mix_btc, targets, dtype=torch.float32, chunk=1, want_outputs=False,
-                       timings=None):
+                       timings=None, pins=None):
     """Loss and gradients of a whole batch, computed `chunk` excerpts at a time so that a full-size
     batch (16 x 147443 samples) never holds more than one chunk's autograd graph in host memory.
     The loss is a mean over excerpts (Training.py:62), so batch loss / gradient = mean of the
     chunk losses / gradients (equal chunk sizes are required).  named_params: [(tf_name, ndarray)].
     Returns (loss float, [grad tensors in variable order], {source: [B,Tout,C]} or None).
-    `timings`, if a list, receives the wall time of each chunk's forward+backward."""
+    `timings`, if a list, receives the wall time of each chunk's forward+backward.
+    pins: prescribed LeakyReLU branches of the whole batch (get_output), sliced per chunk."""
     import time
     cfg = shapes.finalize_config(cfg)
     B = mix_btc.shape[0]
@@ -298,7 +332,8 @@ def chunked_train_step(cfg, named_params, mix_btc, targets, dtype=torch.float32,
         ttg = {k: torch.as_tensor(v[lo:lo + chunk]).to(dtype) for k, v in targets.items()}
         for _, p in tp:
             p.grad = None
-        o = get_output(cfg, tp, tmix, True)
+        cp = None if pins is None else {k: (v[0][lo:lo + chunk], v[1][lo:lo + chunk]) for k, v in pins.items()}
+        o = get_output(cfg, tp, tmix, True, pins=cp)
         loss = separator_loss(cfg, o, ttg)
         loss.backward()
         if timings is not None:

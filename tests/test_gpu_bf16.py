@@ -277,6 +277,30 @@ def test_bf16_full_size_m4_baseline_stereo(lib):
     assert sep.plan_info().output_frames == 16389
 
 
+def test_bf16_full_size_m5_full_learned_upsampling(lib):
+    """M5 `full` (Config.py:80-88: context + stereo + difference output + LEARNED upsampling) at full size
+    (147443 -> 16389), B = 2, in the bf16 mode: the interpolation weights and their gradients ride on bf16 activations."""
+    over = dict(output_type="difference", context=True, mono_downmix=False, upsampling="learned")
+    ocfg = shapes.finalize_config(dict(shapes.BASE_MODEL_CONFIG, **over))
+    sep = _step(over, ocfg, golden_params(ocfg, 93), 2, 16384, 94, "bf16_M5_full_learned_B2")
+    assert sep.plan_info().output_frames == 16389
+
+
+@pytest.mark.parametrize("tune", [False, True], ids=["heuristic", "tuned"])
+def test_bf16_deep_variant_l16_f48(lib, tune):
+    """BASELINE.json configs[4] -- 16 levels, 48 base channels, stereo, 4 sources, same padding -- in the dtype that
+    config states (bf16): outputs, loss and all 68 gradient tensors against the FLOAT64 oracle at the bf16 mode's
+    bounds.  2 * 2^16-sample excerpts (as test_deep_variant_tuned_all_gradients_vs_float64: the float64 autograd graph
+    then fits in a few GB of host memory; a same-padding model exercises every level and tile family of the full-size
+    plan, only the number of time tiles per launch differs), batch 2, heuristic and autotuned tilings."""
+    over = dict(num_layers=16, num_initial_filters=48, mono_downmix=False, task="multi_instrument",
+                output_type="difference")
+    ocfg = shapes.finalize_config(dict(shapes.BASE_MODEL_CONFIG, **over))
+    sep = _step(over, ocfg, golden_params(ocfg, 95), 2, 2 * 65536, 96, "bf16_deep_l16_f48_%s" % ("tuned" if tune else "heuristic"),
+                tune=tune)
+    assert len(sep._active.tensors) == 68
+
+
 def test_bf16_mode_leaves_fp32_mode_alone(lib):
     """The same separator class in the default mode is still the exact-fp32 path (no bf16 rounding)."""
     case = GOLDEN_CASES["baseline_context_small"]

@@ -29,7 +29,9 @@ OUT_TOL = 5e-6       # absolute, outputs are O(1)
 LOSS_TOL = 2e-6      # relative
 GRAD_TOL = 5e-4      # x max|g| per tensor, vs the float64 oracle
 GRAD_TOL_FULL_TUNED = 1e-3   # the B = 16 headline plan under its tuned table: max-norm on the LeakyReLU sign floor (see the test)
-GRAD_L2_TOL = 5e-4   # per conv kernel ||g - ref||_2 / ||ref||_2 at full size (observed 1.0e-4 .. 1.3e-4 with flips, ~1e-6 without)
+GRAD_L2_TOL = 2.6e-4 # per conv kernel ||g - ref||_2 / ||ref||_2 at full size vs the FREE float64 oracle: 2x the observed 1.0e-4 .. 1.3e-4
+                     # (LeakyReLU branch flips included; ~1e-6 without)
+GRAD_TOL_PINNED = 2e-5   # x max|g| per tensor vs the float64 oracle evaluated on the kernels' own LeakyReLU branches (_gpu_pins)
 
 import wave_u_net_amd as wun                      # noqa: E402
 from wave_u_net_amd import _lib                   # noqa: E402
@@ -313,6 +315,64 @@ def _grad_rel_l2(sep, tp, ograds):
         if e > w[0]:
             w = (e, n)
     return w
+
+
+def _gpu_pins(sep, ocfg):
+    """The LeakyReLU branch every conv output of the last get_output(training=True) fell on, read back from the
+    workspace (wun_plan_activation), as `pins` for the oracle (oracle/waveunet_torch.py: leaky_relu): name -> (pos, known)
+    bool tensors of the layer's full conv-output shape.  Post-activation values keep the pre-activation's sign, so
+    pos = (stored value > 0).  A down level keeps two tensors -- the decimated stream (even positions, what the next
+    level reads) and the skip window (what crop_and_concat reads); with context they come from two launches whose
+    summation orders differ, so the same conv output can sit on different sides of 0 in the two: "down<i>" pins the
+    value the skip connection sees, "down<i>/dec" the value the decimation sees.  Positions the kernels never compute
+    (odd outputs outside the crop window, context mode: dead work) stay unpinned."""
+    L, same = ocfg["num_layers"], not ocfg["context"]
+    Kd = ocfg["filter_size"]
+    B = int(sep._active.info.batch)
+    t = int(sep._active.info.input_frames)
+    pins = {}
+
+    def place(shape, view, t0, tstep):
+        pos = torch.zeros(shape, dtype=torch.bool)
+        known = torch.zeros(shape, dtype=torch.bool)
+        v = view.cpu()
+        n = v.shape[2]
+        pos[:, :, t0:t0 + n * tstep:tstep] = v > 0
+        known[:, :, t0:t0 + n * tstep:tstep] = True
+        return pos, known
+
+    for i in range(L):
+        t_conv = t if same else t - Kd + 1
+        v, t0, ts = sep.activation("skip", i)
+        shape = (B, v.shape[1], t_conv)
+        pins["down%d" % i] = place(shape, v, t0, ts)
+        if not same:
+            vd, t0d, tsd = sep.activation("dec", i)
+            assert (t0d, tsd) == (0, 2) and vd.shape[2] == (t_conv + 1) // 2
+            pins["down%d/dec" % i] = place(shape, vd, t0d, tsd)
+        t = (t_conv + 1) // 2
+    v, t0, ts = sep.activation("bottleneck")
+    pins["bottleneck"] = place(tuple(v.shape), v, t0, ts)
+    for j in range(L):
+        v, t0, ts = sep.activation("up", j)
+        pins["up%d" % j] = place(tuple(v.shape), v, t0, ts)
+    return pins
+
+
+def _count_flips(ocfg, params, mix, pins):
+    """(number of pinned LeakyReLU inputs whose float64 value lies on the other side of 0 than the kernels' fp32 value,
+    number of pinned inputs) -- evaluated excerpt by excerpt with the FREE float64 oracle."""
+    tp = wt.params_to_torch(params, torch.float64, requires_grad=False)
+    flips = total = 0
+    with torch.no_grad():
+        for b in range(mix.shape[0]):
+            _, inter = wt.get_output(ocfg, tp, torch.as_tensor(mix[b:b + 1]).double(), True, return_intermediates=True)
+            for name, (pos, known) in pins.items():
+                y = inter[name.split("/")[0]]
+                k = known[b:b + 1]
+                flips += int(((y > 0) != pos[b:b + 1])[k].sum())
+                total += int(k.sum())
+    return flips, total
 
 
 def _loss_check(loss, oloss, tag):
@@ -819,6 +879,20 @@ def test_benchmarked_configuration_b16_tuned_vs_oracle(lib):
     l2, which = _grad_rel_l2(sep, tp, ograds)
     record("gradients_rel_l2_vs_float64_oracle", "bench_config_B16_tuned (worst: %s)" % which, l2, GRAD_L2_TOL)
     assert l2 <= GRAD_L2_TOL, (l2, which)
+    # ... and what is left when the float64 oracle takes the SAME LeakyReLU branches as the kernels did (their masks
+    # read back from the workspace): the arithmetic alone.  If the 1e-4 .. 5e-4 above were anything but branch flips --
+    # a B-dependent defect, a split-K order issue in the batch-folded tiles that only engage at B = 16 -- it would
+    # still be here; bound 2e-5.
+    pins = _gpu_pins(sep, ocfg)
+    flips = _count_flips(ocfg, params, hmix, pins)
+    ploss, pgrads, pouts = wt.chunked_train_step(ocfg, params, hmix, htg, dtype=torch.float64, chunk=1, want_outputs=True, pins=pins)
+    _out_check(outs, pouts, names, "bench_config_B16_tuned (branch-pinned oracle)")
+    _loss_check(loss.item(), ploss, "bench_config_B16_tuned (branch-pinned oracle)")
+    e_pin = _grad_check(sep, tp, pgrads, tol=GRAD_TOL_PINNED, tag="bench_config_B16_tuned (branch-pinned float64 oracle; %d of %d "
+                        "LeakyReLU inputs on the other side of 0 in float64)" % flips)
+    l2p, whichp = _grad_rel_l2(sep, tp, pgrads)
+    record("gradients_rel_l2_vs_float64_oracle", "bench_config_B16_tuned (branch-pinned; worst: %s)" % whichp, l2p, GRAD_TOL_PINNED)
+    assert l2p <= GRAD_TOL_PINNED and e_pin <= GRAD_TOL_PINNED, (e_pin, l2p, whichp)
     # ... and the same table with its forward entries reset (heuristic forward kernels, tuned backward kernels): other
     # masks, same bounds
     if text is not None and tr.tune_source == "pinned":

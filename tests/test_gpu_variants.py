@@ -61,7 +61,9 @@ def _t_out(T, K, stride, same):
 # (B, Cin, Cout, K, T, same)  -- chosen so that, between them, every tile variant is a legal choice:
 # N = 48 admits 32/48/64/80-column tiles, N = 96 admits 96/128-column tiles, T >= 400 admits 384-row
 # tiles, the 1-/2-channel cases admit the 4-channel-chunk audio-input tiles, the B = 16 short cases
-# the batch-folded tiles; the last three the register-window tiles of wun_conv_win.hip.
+# the batch-folded tiles.  (Variants 42..55 are a RETIRED index range -- round 4's register-window conv tiles, removed in
+# round 5; the range stays reserved so the in-workgroup split-K tiles keep their numbers in committed tuning tables.)
+RETIRED_VARIANTS = range(42, 56)
 SWEEP_CASES = [
     (2, 24, 48, 15, 800, False),
     (2, 40, 96, 5, 420, True),
@@ -72,7 +74,7 @@ SWEEP_CASES = [
     (16, 48, 96, 15, 95, False),
     (6, 72, 48, 5, 77, True),
     (16, 24, 64, 15, 151, False),
-    # the register-window tiles (variants >= 42) want 16-byte aligned output rows: lengths whose outputs are multiples of 4
+    # 16-byte aligned output rows (lengths whose outputs are multiples of 4)
     (2, 24, 48, 15, 814, False),
     (2, 48, 96, 15, 814, False),
     (2, 48, 80, 5, 404, False),
@@ -328,7 +330,8 @@ def test_conv_dma_staging_equals_register_staging(lib, case, monkeypatch):
 
 def test_every_conv_variant_was_exercised(lib):
     nvar = lib.wun_op_num_conv_variants()
-    missing = [v for v in range(nvar) if v not in _RAN_CONV]
+    assert not (set(RETIRED_VARIANTS) & set(_RAN_CONV)), "a retired variant index was launched"
+    missing = [v for v in range(nvar) if v not in _RAN_CONV and v not in RETIRED_VARIANTS]
     assert not missing, "conv tile variants never checked: %s" % missing
     kinds = set().union(*_RAN_CONV.values())
     assert kinds == {"stride1", "stride2", "two_source_accum_mask", "strided_output", "fused_two_phase"}, kinds
@@ -506,7 +509,7 @@ def test_narrow_wgrad_operator(lib, case):
     dxg, dzg = _cuda(x), _cuda(dz)
     _lib.check(lib.wun_op_set_wgrad_narrow(1))
     try:
-        scr = torch.empty(int(lib.wun_op_conv1d_wgrad_scratch(B, Cin, Cout, K, t_out)) + (1 << 20), device="cuda")
+        scr = torch.empty(int(lib.wun_op_conv1d_wgrad_scratch(B, Cin, Cout, K, t_out)), device="cuda")
         gdw = torch.full((K, Cin, Cout), float("nan"), device="cuda")
         gdb = torch.full((Cout,), float("nan"), device="cuda")
         _lib.check(lib.wun_op_conv1d_wgrad(dxg.data_ptr(), dzg.data_ptr(), gdw.data_ptr(), gdb.data_ptr(), scr.data_ptr(),

@@ -110,3 +110,43 @@ def test_synthetic_batch_contract():
     for v in tg.values():
         assert v.shape == (2, 45, 2)
     assert np.abs(mix).max() <= 1.0
+
+
+@pytest.mark.parametrize("name", ["baseline_context_small", "full_small", "baseline_small"])
+def test_branch_pinned_leaky_relu_is_the_free_oracle_on_its_own_branches(name):
+    """oracle/waveunet_torch.py: `pins` (the LeakyReLU branches of the HIP kernels, read back by the GPU parity test)
+    must not change anything when they prescribe the branches the oracle takes anyway -- outputs and loss bit for
+    bit, every gradient to float64 rounding -- and must act when one branch is flipped (that element's derivative 1 <-> 0.2)."""
+    case = GOLDEN_CASES[name]
+    cfg = _cfg(case)
+    params = golden_params(cfg, case["seed"])
+    B = 2
+    i, o = shapes.get_padding(cfg, [B, case["frames"], 0])
+    mix, targets = wt.synthetic_batch(cfg, B, i[1], o[1], seed=7)
+    tp = wt.params_to_torch(params, torch.float64)
+    _, inter = wt.get_output(cfg, tp, torch.tensor(mix, dtype=torch.float64), True, return_intermediates=True)
+    pins = {}
+    for k, y in inter.items():
+        pins[k] = (y > 0, torch.ones_like(y, dtype=torch.bool))
+        if k.startswith("down"):
+            known = torch.zeros_like(y, dtype=torch.bool)
+            known[:, :, ::2] = True                               # the decimated copy: even positions only
+            pins[k + "/dec"] = (y > 0, known)
+    l0, g0, o0 = wt.chunked_train_step(cfg, params, mix, targets, dtype=torch.float64, chunk=1, want_outputs=True)
+    l1, g1, o1 = wt.chunked_train_step(cfg, params, mix, targets, dtype=torch.float64, chunk=1, want_outputs=True, pins=pins)
+    assert l0 == l1
+    for a, b in zip(g0, g1):
+        # (equal up to float64 rounding, not bit for bit: with "down<i>/dec" the pre-activation collects its gradient
+        #  from two LeakyReLU nodes instead of one, i.e. in another summation order)
+        assert (a - b).abs().max().item() <= 1e-13 * max(a.abs().max().item(), 1e-30)
+    for n in o0:
+        assert torch.equal(o0[n], o1[n])
+    # flip the branch of the smallest-magnitude input of the first up conv: its weight gradient moves
+    y = inter["up0"]
+    idx = torch.argmin(y.abs())
+    pos, known = pins["up0"]
+    pos = pos.clone()
+    pos.view(-1)[idx] = ~pos.view(-1)[idx]
+    pins["up0"] = (pos, known)
+    _, g2, _ = wt.chunked_train_step(cfg, params, mix, targets, dtype=torch.float64, chunk=1, pins=pins)
+    assert any((a - b).abs().max().item() > 1e-9 * a.abs().max().item() for a, b in zip(g0, g2))

@@ -22,6 +22,10 @@ class WunPlanInfo(C.Structure):
                 ("fwd_flops_dense", C.c_double)]
 
 
+class WunActivationInfo(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("offset", "batch_stride", "pitch", "channels", "frames", "t0", "tstep")]
+
+
 class WunTensorInfo(C.Structure):
     _fields_ = [("name", C.c_char * 64), ("offset", C.c_int64), ("ndim", C.c_int32),
                 ("shape", C.c_int64 * 4)]
@@ -35,6 +39,7 @@ _SIGS = {
     "wun_plan_destroy": (None, [_P]),
     "wun_plan_query": (C.c_int, [_P, C.POINTER(WunPlanInfo)]),
     "wun_plan_tensor": (C.c_int, [_P, C.c_int64, C.POINTER(WunTensorInfo)]),
+    "wun_plan_activation": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(WunActivationInfo)]),
     "wun_forward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _P]),
     "wun_loss_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "wun_loss_backward_ex": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.c_int32]),

@@ -66,19 +66,12 @@ struct ConvArgs {
     // storing d_up, the split-K epilogue writes ubw_dz[b][c][i] = (d_up[2i] + wa d_up[2i+1] + 1/2 d_up[2i-1]) *
     // LeakyReLU'(ubw_x[b][c][i]) -- the arithmetic of upsample_bwd_vec_kernel; rows of ubw_dz / ubw_x share one geometry.
     float* ubw_dz; const float* ubw_x; long long ubw_bs; int ubw_pitch; int ubw_n;
-    // the same weights as W in the "window layout" [Ctot][ceil(KW / 4)][N][4 taps] (written per step by pack_win_kernel), or
-    // null: what the register-window conv kernel (wun_conv_win.hip, variants >= WUN_FIRST_WIN_VARIANT) reads
-    const float* Wwin;
 };
-#define WUN_FIRST_WIN_VARIANT 42     // conv tile variants [42, 42 + conv_win_num_variants()): conv_win_kernel tiles
-struct WinPackDesc { long long src_off, dst_off; int K, C, N, src_in_ws; };   // one conv's weights -> window layout
-bool conv_win_ok(const ConvArgs& a, int wv);
-int conv_win_num_variants();
-int conv_win_pick(const ConvArgs& a);
-size_t conv_win_lds_bytes(const ConvArgs& a, int wv);
-hipError_t launch_conv_win(const ConvArgs& a, int wv, hipStream_t s);
-hipError_t launch_pack_win(const float* params, float* ws, const WinPackDesc* dev_descs, int ndesc, long long max_vecs,
-                           hipStream_t s);
+// Conv tile variants [42, 56) were the register-window conv tiles of round 4 (per launch on par with the DMA-staged
+// conv_mfma_kernel tiles, 0.5 % slower per step; removed in round 5).  The index range stays RETIRED -- never a legal
+// choice -- so that the in-workgroup split-K tiles keep their numbers (56 ..) and committed tuning tables stay valid.
+#define WUN_FIRST_RETIRED_VARIANT 42
+#define WUN_NUM_RETIRED_VARIANTS 14
 // did the last launch_conv() on this thread write the fused upsampled copy?  (only split-K launches do)
 int conv_last_fused_ups();
 __host__ __device__ static inline bool conv_acc_at(const ConvArgs& a, int pos) { return (unsigned)(pos - a.acc_lo) < a.acc_len; }

@@ -1279,7 +1279,7 @@ size_t conv_lds_bytes(const ConvArgs& a, int variant) {
         const size_t red = (size_t)(WUN_KG - 1) * kConvVariants[bv].MT * kConvVariants[bv].NW * 256 * 16;   // accumulator hand-over
         return stage > red ? stage : red;
     }
-    if (variant >= WUN_FIRST_WIN_VARIANT) return conv_win_lds_bytes(a, variant - WUN_FIRST_WIN_VARIANT);
+    if (variant >= WUN_FIRST_RETIRED_VARIANT) return (size_t)1 << 30;             // retired index range: never launched
     int TT, NT, J, XP, WP;
     conv_geom(a, variant, TT, NT, J, XP, WP);
     const int CK = kConvVariants[variant].CK;
@@ -1426,7 +1426,7 @@ bool conv_choice_ok(const ConvArgs& a, long long part_cap, int v, int ks) {
         const long long per = (long long)a.B * a.N * ((a.Tout + 3) & ~3);
         return ks == 1 || (long long)ks * per <= part_cap;
     }
-    if (v >= WUN_FIRST_WIN_VARIANT) return ks == 1 && conv_win_ok(a, v - WUN_FIRST_WIN_VARIANT);     // register-window tiles
+    if (v >= WUN_FIRST_RETIRED_VARIANT) return false;                // retired index range (wun_internal.h)
     if (v < 0 || v >= nvar || ks < 1) return false;
     const int Ctot = a.C0 + a.C1;
     const bool phase2 = (a.flags & F_PHASE2) != 0;
@@ -1468,8 +1468,8 @@ int conv_list_candidates(const ConvArgs& a, long long part_cap, ConvChoice* out,
     return n;
 }
 
-static_assert(sizeof(kConvVariants) / sizeof(kConvVariants[0]) == WUN_FIRST_WIN_VARIANT, "window variants follow the tile table");
-static int first_k3_variant() { return WUN_FIRST_WIN_VARIANT + conv_win_num_variants(); }
+static_assert(sizeof(kConvVariants) / sizeof(kConvVariants[0]) == WUN_FIRST_RETIRED_VARIANT, "the retired index range follows the tile table");
+static int first_k3_variant() { return WUN_FIRST_RETIRED_VARIANT + WUN_NUM_RETIRED_VARIANTS; }
 int conv_num_variants() { return first_k3_variant() + kNumK3; }
 
 
@@ -1515,11 +1515,6 @@ hipError_t launch_conv(const ConvArgs& a_in, float* part, long long part_cap, hi
     if (a.force_variant > 0 && vecw) {
         v = a.force_variant - 1;
         if (!conv_choice_ok(a, part != nullptr ? part_cap : 0, v, a.force_ksplit > 0 ? a.force_ksplit : 1)) return hipErrorInvalidValue;
-    } else if (vecw && a.Wwin != nullptr) {
-        // heuristic: a register-window tile where the launch qualifies and fills the chip without split-K
-        static const bool win_default = getenv("WUN_CONV_WIN_DEFAULT") == nullptr || atoi(getenv("WUN_CONV_WIN_DEFAULT")) != 0;
-        const int wv = win_default ? conv_win_pick(a) : -1;
-        if (wv >= 0 && (long long)a.B * ((a.Tout + 255) / 256) * ((a.N + 47) / 48) >= 256) v = WUN_FIRST_WIN_VARIANT + wv;
     }
     if (is_k3(v)) {
         const int bv = conv_tile_variant(v);
@@ -1538,7 +1533,7 @@ hipError_t launch_conv(const ConvArgs& a_in, float* part, long long part_cap, hi
 #undef WUN_K3
 #undef WUN_K3F
     }
-    if (v >= WUN_FIRST_WIN_VARIANT) return launch_conv_win(a, v - WUN_FIRST_WIN_VARIANT, s);
+    if (v >= WUN_FIRST_RETIRED_VARIANT) return hipErrorInvalidValue;
 #ifdef WUN_ABLATION
     if (const char* e = getenv("WUN_VARIANT")) v = atoi(e);
 #endif
@@ -2556,9 +2551,46 @@ __global__ void btc_to_ncw_kernel(const float* __restrict__ src, float* __restri
     }
 }
 
+// The same copy for the audio tensors the reference feeds (1 or 2 channels, UnetAudioSeparator.py:27): grid y = excerpt,
+// a thread owns 4 consecutive time steps of every channel -- no index divisions, one 16-byte store per channel row
+// (rows of the NCW buffer are 16-byte aligned; the [B, T, C] source rows are not for odd T, so it is read by dwords,
+// which coalesce across the wave all the same).  For C = 1 the two layouts hold the same samples in the same order;
+// the copy only re-pitches the rows to the 16-byte aligned form every consumer's vector / DMA loads are written for.
+template <int C>
+__global__ __launch_bounds__(256) void btc_to_ncw_vec_kernel(const float* __restrict__ src, float* __restrict__ dst, int T,
+                                                            int pitch) {
+    const int b = blockIdx.y;
+    const int t0 = ((int)blockIdx.x * 256 + (int)threadIdx.x) * 4;
+    if (t0 >= T) return;
+    const float* sp = src + ((long long)b * T + t0) * C;
+    float v[4][C];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < C; ++c) v[r][c] = (t0 + r < T) ? sp[r * C + c] : 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        float* dp = dst + ((long long)b * C + c) * pitch + t0;
+        if (t0 + 3 < T) {
+            *reinterpret_cast<f32x4*>(dp) = (f32x4){v[0][c], v[1][c], v[2][c], v[3][c]};
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (t0 + r < T) dp[r] = v[r][c];
+        }
+    }
+}
+
 hipError_t launch_btc_to_ncw(const float* src, float* dst, int B, int T, int C, int pitch,
                              hipStream_t s) {
     const long long total = (long long)B * T * C;
+    if ((C == 1 || C == 2) && (pitch & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0 && B <= 65535) {
+        ProfScope ps("btc_to_ncw_kernel", 0.0, s, "", 8.0 * (double)total);
+        const dim3 grid((unsigned)((T + 1023) / 1024), (unsigned)B);
+        if (C == 1) hipLaunchKernelGGL(btc_to_ncw_vec_kernel<1>, grid, dim3(256), 0, s, src, dst, T, pitch);
+        else hipLaunchKernelGGL(btc_to_ncw_vec_kernel<2>, grid, dim3(256), 0, s, src, dst, T, pitch);
+        return hipGetLastError();
+    }
     long long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     ProfScope ps("btc_to_ncw_kernel", 0.0, s, "", 8.0 * (double)total);

@@ -282,7 +282,9 @@ __global__ __launch_bounds__(64 * (24 / NPW)) void narrow_stream_kernel(NarrowWg
 // shapes the streaming form serves: one input channel, all rows on four waves of NPW = 6, taps <= 15
 static bool narrow_stream_ok(const NarrowWgradArgs& a) {
     static const bool off = getenv("WUN_NO_NARROW_STREAM") != nullptr && atoi(getenv("WUN_NO_NARROW_STREAM")) != 0;
-    return !off && a.C0 + a.C1 == 1 && a.N <= 24 && a.KW >= 4 && a.KW <= 15;
+    // (the kernel reads src0 only, in 256-position units)
+    static_assert(WUN_NW_TQ == 256, "narrow_stream_kernel walks units of 4 positions x 64 lanes");
+    return !off && a.C0 == 1 && a.C1 == 0 && a.N <= 24 && a.KW >= 4 && a.KW <= 15;
 }
 
 // out element (k, ci, n = s*Nper + c) -> source s: weights [K][Ctot][Nper] at woff[s], bias at boff[s].

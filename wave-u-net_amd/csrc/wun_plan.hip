@@ -152,13 +152,6 @@ struct wun_plan {
     int npack_fwd = 0;
     long long pack_max = 0;
     PackDesc* dev_pack = nullptr;
-    // exact fp32: "window layout" copies [C][ceil(K/4)][N][4] of the conv weights for the register-window conv kernel
-    // (wun_conv_win.hip), keyed like bf_img; forward weights first, then the stride-1 input-gradient weights
-    std::map<std::pair<int, long long>, long long> win_img;  // (1 = in workspace, float offset) -> float offset of the copy
-    std::vector<WinPackDesc> winp;
-    int nwinp_fwd = 0;
-    long long winp_max = 0;
-    WinPackDesc* dev_winp = nullptr;
     mutable const float* cur_params = nullptr;
     mutable const float* cur_ws = nullptr;
 };
@@ -349,30 +342,6 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
     p->bott.wt_full = add_wt(p->bott, Kd, Kd - 1, 1);
     for (int j = 0; j < L; ++j) p->up[j].wt_full = add_wt(p->up[j], Ku, Ku - 1, 1);
 
-    // ---- exact fp32: window-layout copies for the register-window conv kernel (15- and 5-tap convs, >= 8 input channels) ----
-    // (opt-in, WUN_CONV_WIN=1: measured on par with conv_mfma_kernel per launch and 0.5 % slower per step with its weight
-    //  pre-pass on the chain -- DESIGN.md section 5f; the tiles stay reachable through the operator test hooks)
-    if (cfg->compute_dtype != 1 && getenv("WUN_CONV_WIN") != nullptr && atoi(getenv("WUN_CONV_WIN")) != 0) {
-        auto add_win = [&](int in_ws, long long src_off, int K, int Cin, int Nout) {
-            if (!(K == 15 || K == 5) || Cin < 8 || (Cin & 3) || (Nout & 3) || Nout < 16) return;
-            WinPackDesc d;
-            d.src_off = src_off; d.K = K; d.C = Cin; d.N = Nout; d.src_in_ws = in_ws;
-            const long long vecs = (long long)Cin * ((K + 3) / 4) * Nout;
-            d.dst_off = bump(w, vecs * 4);
-            p->winp.push_back(d);
-            p->win_img[{in_ws, src_off}] = d.dst_off;
-            if (vecs > p->winp_max) p->winp_max = vecs;
-        };
-        for (int i = 1; i < L; ++i) add_win(0, p->down[i].woff, p->down[i].KW, p->down[i].Cin, p->down[i].Cout);
-        add_win(0, p->bott.woff, p->bott.KW, p->bott.Cin, p->bott.Cout);
-        for (int j = 0; j < L; ++j) add_win(0, p->up[j].woff, p->up[j].KW, p->up[j].Cin, p->up[j].Cout);
-        p->nwinp_fwd = (int)p->winp.size();
-        // stride-1 input gradients: wt_full is [K][Cout][Cin], i.e. a conv from Cout to Cin channels
-        for (int i = 1; i < L; ++i) add_win(1, p->down[i].wt_full, p->down[i].KW, p->down[i].Cout, p->down[i].Cin);
-        add_win(1, p->bott.wt_full, p->bott.KW, p->bott.Cout, p->bott.Cin);
-        for (int j = 0; j < L; ++j) add_win(1, p->up[j].wt_full, p->up[j].KW, p->up[j].Cout, p->up[j].Cin);
-    }
-
     // ---- bf16 mode: packed weight images (every conv with >= 8 input channels; the audio-input conv and the
     // output head stay exact fp32) ----
     p->bf16 = cfg->compute_dtype == 1;
@@ -411,22 +380,32 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
     // (bf16 speed mode: rows come in slots of 16 channels x 1 tap, up to 32 slots per row group)
     const long long rowpad = p->bf16 ? 1024 : 384;
     auto blockf = [rowpad](const ConvLayer& cl) { return ((long long)cl.KW * (cl.Cin + 15) + 1 + rowpad) * (cl.Cout + 80); };
+    // one part of a layer's weight gradient under BOTH exact-fp32 kernels: the LDS-tiled one (tile-major partial
+    // blocks) and -- where it serves the shape -- the register-window one, whose split policy differs (it always aims
+    // at 1024 workgroups and counts units of its own length) and whose partial blocks have the final layout
+    auto need = [&](const WgradArgs& w, const ConvLayer& cl) {
+        long long n = (long long)wgrad_pick_nsplit(w) * blockf(cl);
+        WgradArgs ww = w;
+        ww.win = 1;
+        if (!p->bf16 && wgrad_win_supported(ww)) n = std::max(n, (long long)wgrad_pick_nsplit(ww) * wgrad_win_partial_floats(ww));
+        return n;
+    };
     for (int i = 0; i < L; ++i) {
         const DownShape& d = p->dsh[i];
-        long long ns;
+        long long n;
         if (same) {
-            ns = wgrad_pick_nsplit(wgrad_shape_only(B, d.cin, 0, Kd, LOADER_DIRECT, d.cout, d.t_conv));
+            n = need(wgrad_shape_only(B, d.cin, 0, Kd, LOADER_DIRECT, d.cout, d.t_conv), p->down[i]);
         } else {
-            ns = wgrad_pick_nsplit(wgrad_shape_only(B, d.cin, 0, Kd, LOADER_DEINT, d.cout, d.t_dec)) +
-                 wgrad_pick_nsplit(wgrad_shape_only(B, d.cin, 0, Kd, LOADER_DIRECT, d.cout, d.tc));
+            n = need(wgrad_shape_only(B, d.cin, 0, Kd, LOADER_DEINT, d.cout, d.t_dec), p->down[i]) +
+                need(wgrad_shape_only(B, d.cin, 0, Kd, LOADER_DIRECT, d.cout, d.tc), p->down[i]);
         }
-        pmax = std::max(pmax, ns * blockf(p->down[i]));
+        pmax = std::max(pmax, n);
     }
-    pmax = std::max(pmax, (long long)wgrad_pick_nsplit(wgrad_shape_only(B, p->bott.Cin, 0, Kd, LOADER_DIRECT, p->c_b, p->t_b)) * blockf(p->bott));
+    pmax = std::max(pmax, need(wgrad_shape_only(B, p->bott.Cin, 0, Kd, LOADER_DIRECT, p->c_b, p->t_b), p->bott));
     for (int j = 0; j < L; ++j)
-        pmax = std::max(pmax, (long long)wgrad_pick_nsplit(wgrad_shape_only(B, p->ush[j].c_skip, p->ush[j].c_cur, Ku, LOADER_DIRECT, p->ush[j].cout, p->ush[j].t_conv)) * blockf(p->up[j]));
+        pmax = std::max(pmax, need(wgrad_shape_only(B, p->ush[j].c_skip, p->ush[j].c_cur, Ku, LOADER_DIRECT, p->ush[j].cout, p->ush[j].t_conv), p->up[j]));
     if (p->Sh > 0)
-        pmax = std::max(pmax, (long long)wgrad_pick_nsplit(wgrad_shape_only(B, C, F, Ko, LOADER_DIRECT, C, p->Tout)) * blockf(p->head[0]));
+        pmax = std::max(pmax, need(wgrad_shape_only(B, C, F, Ko, LOADER_DIRECT, C, p->Tout), p->head[0]));
     pmax *= 4;                                              // two streams' halves, each with 2x headroom for the autotuner's split counts
     p->partial_floats = pmax;
     p->partial_off = bump(w, pmax);
@@ -460,11 +439,6 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
             (void)hipGetLastError();
         }
     }
-    if (!p->winp.empty()) {
-        hipError_t e = hipMalloc((void**)&p->dev_winp, p->winp.size() * sizeof(WinPackDesc));
-        if (e == hipSuccess) e = hipMemcpy(p->dev_winp, p->winp.data(), p->winp.size() * sizeof(WinPackDesc), hipMemcpyHostToDevice);
-        if (e != hipSuccess) { p->dev_winp = nullptr; p->win_img.clear(); (void)hipGetLastError(); }
-    }
     if (!p->pack.empty()) {
         hipError_t e = hipMalloc((void**)&p->dev_pack, p->pack.size() * sizeof(PackDesc));
         if (e == hipSuccess) e = hipMemcpy(p->dev_pack, p->pack.data(), p->pack.size() * sizeof(PackDesc), hipMemcpyHostToDevice);
@@ -478,7 +452,6 @@ extern "C" void wun_plan_destroy(wun_plan* p) {
     if (!p) return;
     if (p->dev_wt) (void)hipFree(p->dev_wt);
     if (p->dev_pack) (void)hipFree(p->dev_pack);
-    if (p->dev_winp) (void)hipFree(p->dev_winp);
     for (auto e : p->events) (void)hipEventDestroy(e);
     if (p->tev0) { (void)hipEventDestroy(p->tev0); (void)hipEventDestroy(p->tev1); }
     if (p->wt_ev) (void)hipEventDestroy(p->wt_ev);
@@ -504,6 +477,20 @@ extern "C" int wun_plan_tensor(const wun_plan* p, int64_t index, wun_tensor_info
     if (!p || !info) return fail(WUN_ERR_INVALID, "null argument");
     if (index < 0 || index >= (int64_t)p->tensors.size()) return fail(WUN_ERR_INVALID, "tensor index out of range");
     *info = p->tensors[(size_t)index];
+    return WUN_OK;
+}
+
+extern "C" int wun_plan_activation(const wun_plan* p, int32_t kind, int32_t index, wun_activation_info* info) {
+    if (!p || !info) return fail(WUN_ERR_INVALID, "null argument");
+    const Buf* b = nullptr;
+    long long t0 = 0, tstep = 1;
+    if (kind == 0 && index >= 0 && index < p->L) { b = &p->dec[(size_t)index]; tstep = 2; }
+    else if (kind == 1 && index >= 0 && index < p->L) { b = &p->skip[(size_t)index]; t0 = p->same ? 0 : p->dsh[(size_t)index].cs; }
+    else if (kind == 2 && index == 0) b = &p->bott_out;
+    else if (kind == 3 && index >= 0 && index < p->L) b = &p->upo[(size_t)index];
+    if (b == nullptr) return fail(WUN_ERR_INVALID, "wun_plan_activation: unknown kind / index");
+    info->offset = b->off; info->batch_stride = b->bs; info->pitch = b->pitch;
+    info->channels = b->C; info->frames = b->T; info->t0 = t0; info->tstep = tstep;
     return WUN_OK;
 }
 
@@ -708,11 +695,6 @@ static hipError_t conv_dispatch(const wun_plan* p, ConvArgs a, float* part, long
             return launch_conv_bf16(a, s);
         }
     }
-    if (!p->bf16 && !p->win_img.empty() && a.W != nullptr) {
-        const bool in_ws = a.W >= p->cur_ws && a.W < p->cur_ws + p->ws;
-        auto it = p->win_img.find({in_ws ? 1 : 0, (long long)(a.W - (in_ws ? p->cur_ws : p->cur_params))});
-        if (it != p->win_img.end()) a.Wwin = p->cur_ws + it->second;
-    }
     if (p->tune_mode == 1) {
         if (vec.size() <= idx) vec.resize(idx + 1, ConvChoice{-1, 0});
         std::vector<ConvChoice> cands_v(640);               // (per call: two plans may be tuned from different threads)
@@ -782,8 +764,6 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
         if (!p->dev_pack) return fail(WUN_ERR_HIP, "plan was created without a usable HIP device");
         HIP_TRY(launch_pack_bf16(params, ws, p->dev_pack, p->npack_fwd, p->pack_max, s));
     }
-    if (!p->bf16 && p->dev_winp && p->nwinp_fwd > 0)
-        HIP_TRY(launch_pack_win(params, ws, p->dev_winp, p->nwinp_fwd, p->winp_max, s));
     p->wt_ready = false;
     if (training && !p->wt.empty() && p->dev_wt && s2 != s) {
         // the backward pass will need tap-flipped / transposed copies of every kernel: make them now,
@@ -793,8 +773,6 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
         HIP_TRY(launch_make_wt(params, ws, p->dev_wt, (int)p->wt.size(), p->wt_max, s2));
         if (p->bf16)
             HIP_TRY(launch_pack_bf16(params, ws, p->dev_pack + p->npack_fwd, (int)p->pack.size() - p->npack_fwd, p->pack_max, s2));
-        if (!p->bf16 && p->dev_winp && (int)p->winp.size() > p->nwinp_fwd)
-            HIP_TRY(launch_pack_win(params, ws, p->dev_winp + p->nwinp_fwd, (int)p->winp.size() - p->nwinp_fwd, p->winp_max, s2));
         HIP_TRY(hipEventRecord(p->wt_ev, s2));
         p->wt_ready = true;
         side_used = true;
@@ -996,7 +974,17 @@ static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const Conv
             q[0].out = out_w; q[0].direct = 1; q[0].split_base = 0;
             return launch_wgrad(q[0], s);
         }
-        if (total * wgrad_partial_floats(q[0]) > pcap) return hipErrorOutOfMemory;
+        // the arena is sized at plan creation for the heuristic split counts with 2x headroom; a policy that asks for
+        // more on some shape gets fewer splits, not a failed step
+        for (int guard = 0; (long long)total * wgrad_partial_floats(q[0]) > pcap && total > nparts && guard < 32; ++guard) {
+            total = 0;
+            for (int i = 0; i < nparts; ++i) { q[i].nsplit = (q[i].nsplit + 1) / 2; total += q[i].nsplit; }
+        }
+        if ((long long)total * wgrad_partial_floats(q[0]) > pcap) return hipErrorOutOfMemory;
+        if (total == 1) {
+            q[0].out = out_w; q[0].direct = 1; q[0].split_base = 0;
+            return launch_wgrad(q[0], s);
+        }
         int done = 0;
         for (int i = 0; i < nparts; ++i) {
             q[i].out = partial; q[i].direct = 0; q[i].split_base = done;
@@ -1291,8 +1279,6 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
         HIP_TRY(launch_make_wt(params, ws, p->dev_wt, (int)p->wt.size(), p->wt_max, s));
         if (p->bf16)
             HIP_TRY(launch_pack_bf16(params, ws, p->dev_pack + p->npack_fwd, (int)p->pack.size() - p->npack_fwd, p->pack_max, s));
-        if (!p->bf16 && p->dev_winp && (int)p->winp.size() > p->nwinp_fwd)
-            HIP_TRY(launch_pack_win(params, ws, p->dev_winp + p->nwinp_fwd, (int)p->winp.size() - p->nwinp_fwd, p->winp_max, s));
     }
     p->cur_params = params; p->cur_ws = ws;
 
@@ -1643,27 +1629,8 @@ static float* op_scratch() {
     return buf;
 }
 
-// window-layout copy of a single operator's weights (the plan makes these once per step; here per call)
-static const float* op_win_weights(const ConvArgs& a, hipStream_t s) {
-    static float* buf = nullptr;
-    static WinPackDesc* dd = nullptr;
-    const long long kOpWinFloats = 16ll << 20;
-    const int Ctot = a.C0 + a.C1;
-    const long long vecs = (long long)Ctot * ((a.KW + 3) / 4) * a.N;
-    if (!(a.KW == 15 || a.KW == 5) || a.W == nullptr || vecs * 4 > kOpWinFloats) return nullptr;
-    if (!buf && hipMalloc((void**)&buf, kOpWinFloats * sizeof(float)) != hipSuccess) { buf = nullptr; (void)hipGetLastError(); return nullptr; }
-    if (!dd && hipMalloc((void**)&dd, sizeof(WinPackDesc)) != hipSuccess) { dd = nullptr; (void)hipGetLastError(); return nullptr; }
-    WinPackDesc d;
-    d.src_off = 0; d.dst_off = 0; d.K = a.KW; d.C = Ctot; d.N = a.N; d.src_in_ws = 0;
-    if (hipMemcpyAsync(dd, &d, sizeof(d), hipMemcpyHostToDevice, s) != hipSuccess) return nullptr;
-    if (hipStreamSynchronize(s) != hipSuccess) return nullptr;                 // (d lives on this stack frame)
-    if (launch_pack_win(a.W, buf, dd, 1, vecs, s) != hipSuccess) return nullptr;
-    return buf;
-}
-
 static hipError_t op_launch_conv(ConvArgs a, hipStream_t s) {
     if (g_op_variant >= 0) { a.force_variant = g_op_variant + 1; a.force_ksplit = (a.flags & F_PHASE2) ? 0 : g_op_ksplit; }
-    if (g_op_variant >= WUN_FIRST_WIN_VARIANT) a.Wwin = op_win_weights(a, s);
     return launch_conv(a, op_scratch(), kOpScratchFloats, s);
 }
 
@@ -1717,8 +1684,18 @@ static long long op_wgrad_part_floats(int batch, int cin, int cout, int k, int t
 
 extern "C" int64_t wun_op_conv1d_wgrad_scratch(int batch, int cin, int cout, int k, int t_out) {
     // split partials (worst case over both loaders) + repacked copies of x (t_in <= 2*t_out + k) and dz
-    const long long part = std::max(op_wgrad_part_floats(batch, cin, cout, k, t_out, LOADER_DIRECT),
-                                    op_wgrad_part_floats(batch, cin, cout, k, t_out, LOADER_DEINT));
+    long long part = std::max(op_wgrad_part_floats(batch, cin, cout, k, t_out, LOADER_DIRECT),
+                              op_wgrad_part_floats(batch, cin, cout, k, t_out, LOADER_DEINT));
+    if (g_op_wg_narrow) {
+        // wun_op_set_wgrad_narrow(1): the direct-reduction kernels keep one (k * cin + 1) * cout vector per split
+        NarrowWgradArgs nw;
+        memset(&nw, 0, sizeof(nw));
+        nw.C0 = cin; nw.KW = k; nw.N = nw.Nper = cout; nw.Tq = t_out; nw.B = batch;
+        for (int stride = 1; stride <= 2; ++stride) {
+            nw.stride = stride;
+            part = std::max(part, (long long)narrow_wgrad_pick_nsplit(nw) * narrow_wgrad_partial_floats(nw));
+        }
+    }
     const long long tin_max = 2ll * t_out + k + 8;
     return part + (long long)batch * cin * pad4((int)tin_max) + (long long)batch * cout * pad4(t_out) + 512;
 }

@@ -1,7 +1,7 @@
 // gfx950: "register-window" form of the exact-fp32 weight / bias gradient (Training.py:77 backward of the convs of
 // UnetAudioSeparator.py:97-125):   dW[k][c][n] = sum_{b,q} x[b][c][S q + k - shift] * dz[b][n][q],   db[n] = sum dz.
 //
-// What the measurements of round 4 say about the fp32 matrix pipe (tools/mfma_power_probe.hip, tools/pp_trace.py): a
+// What the measurements of round 4 say about the fp32 matrix pipe (tools/mfma_power_probe.hip): a
 // dense v_mfma_f32_16x16x4_f32 stream fed by ALIGNED 16-byte LDS reads runs at 33.2 cycles per MFMA from one wave per
 // SIMD (32.3 from two); wgrad_mfma_kernel's stream -- one 4-byte LDS read per operand and k-step, rows at arbitrary
 // 4-byte alignment -- needs 36.5-37.6 whoever else shares the SIMD, and every VALU instruction of the staging code
@@ -44,6 +44,12 @@ __device__ __forceinline__ const float* win_sgpr_ptr(const float* q) {
     return (const float*)(((unsigned long long)hi << 32) | lo);
 }
 // one LDS-DMA instruction in its scalar-base form: 64 lanes x 16 bytes from sbase + voff[lane] to LDS bytes m0 + 16 lane
+// (M0 is written inside the statement and NOT declared as a clobber: M0 is a reserved register for LLVM's AMDGPU backend,
+//  naming it in a clobber list is diagnosed as "may lead to undefined behaviour" (-Winline-asm) -- the backend never keeps
+//  a live value in M0 across an asm statement, it re-materialises M0 immediately before every instruction of its own that
+//  reads it (checked in the disassembly of the __builtin_amdgcn_global_load_lds calls of the edge / slow paths below:
+//  each is preceded by its own s_mov_b32 m0).  tools/m0_check.sh verifies that pairing on the disassembly: 1378 LDS-DMA
+//  instructions in this file, none without a fresh M0 write.)
 __device__ __forceinline__ void win_dma16(unsigned m0v, unsigned voff, const float* sbase) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m0v), "v"(voff), "s"(sbase) : "memory");
 }

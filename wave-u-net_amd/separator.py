@@ -286,5 +286,17 @@ class UnetAudioSeparator(object):
             self.adam_m.data_ptr(), self.adam_v.data_ptr(), self.global_step, lr, beta1, beta2, eps,
             grad_scale, self._stream()))
 
+    def activation(self, kind, index=0):
+        """(tensor view [B, C, frames], t0, tstep) of a forward activation kept in the workspace of the last
+        get_output(training=True): kind "dec" / "skip" (down level `index`), "bottleneck", "up" (up conv `index`);
+        element j of a row is the post-activation conv output at position t0 + j * tstep (wun_plan_activation)."""
+        info = _lib.WunActivationInfo()
+        _lib.check(self._lib.wun_plan_activation(self._active.handle, {"dec": 0, "skip": 1, "bottleneck": 2, "up": 3}[kind],
+                                                 int(index), C.byref(info)))
+        B = int(self._active.info.batch)
+        flat = self._ws[self._last_key][info.offset:info.offset + B * info.batch_stride]
+        view = flat.view(B, int(info.channels), int(info.pitch))[:, :, :int(info.frames)]
+        return view, int(info.t0), int(info.tstep)
+
     def plan_info(self):
         return self._active.info if self._active is not None else None
