@@ -718,7 +718,7 @@ def test_leaky_relu_tie_digital_silence(lib, name):
     tp2 = wt.params_to_torch(params, torch.float64, requires_grad=True)
     old = wt.leaky_relu
     try:
-        wt.leaky_relu = lambda x: torch.maximum(0.2 * x, x)
+        wt.leaky_relu = lambda x, pin=None: torch.maximum(0.2 * x, x)
         _, g_split = wt.train_step(ocfg, tp2, tmix, ttg)
     finally:
         wt.leaky_relu = old

@@ -3,11 +3,11 @@
 //   D[time 16][cout 16] += A[time][k] * B[k][cout]   on v_mfma_f32_16x16x32_bf16 (fp32 accumulate)
 //   k = (tap, input channel); one MFMA consumes 32 input channels of one tap.
 //
-// Operands are rounded to bf16 (round-to-nearest-even) when they are staged into LDS; everything
-// in HBM -- activations, gradients, master weights, Adam state -- stays fp32, and the accumulators,
-// bias, activation, mask and accumulate of the epilogue are fp32 exactly as in the exact-fp32
-// kernel (the accumulator fragment layout of the two MFMA shapes is identical, so the epilogue is
-// the same code).  Lane l of a wave supplies A[i = l&15][k = 8*(l>>4) .. +7] and
+// ACTIVATIONS AND THEIR GRADIENTS LIVE IN HBM AS bf16 (round 5): the input rows this kernel reads are bf16 NCW rows
+// (rounded once, by the epilogue that produced them: nearest even, v_cvt_pk_bf16_f32), and its own epilogue -- fp32
+// accumulators, bias, activation, mask, accumulate exactly as in the exact-fp32 kernel (the accumulator fragment layout
+// of the two MFMA shapes is identical) -- rounds once more on the store (ConvArgs.obf; obf = 0 stores fp32: the
+// single-operator tests).  Master weights, weight gradients and the Adam state stay fp32.  Lane l of a wave supplies A[i = l&15][k = 8*(l>>4) .. +7] and
 // B[k = 8*(l>>4) .. +7][j = l&15] and receives D[i = 4*(l>>4)+r][j = l&15].
 //
 // LDS images (per pipeline buffer):
@@ -18,12 +18,14 @@
 //      bf16 weight image (pack_bf16_kernel), so a B fragment is one aligned 16-byte read and 16
 //      lanes read 256 contiguous bytes
 // Pipeline: stage = (NCK chunks of 32 channels) x all taps; while the MFMAs of stage s run, the weights
-// of stage s+1 stream global -> LDS (global_load_lds) and its input window is fetched into registers,
-// rounded and written to the other LDS buffer afterwards; one barrier per stage.
+// of stage s+1 stream global -> LDS (global_load_lds) and its input window is fetched into registers
+// (dword loads: two consecutive time steps of one channel), transposed to [time][8 channels] with v_perm_b32 and
+// written to the other LDS buffer afterwards; one barrier per stage.
 #include "wun_internal.h"
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace wun {
 
@@ -46,11 +48,18 @@ __device__ __forceinline__ int xcd_block(int bid, int grid) {
 
 #define WUN_BF_KMAX 15         // taps
 
+// F_ACCUM applies to the row positions [lo, lo + len) only (ConvArgs.acc_lo / acc_len)
+__device__ __forceinline__ bool conv_acc_pos(int lo, unsigned len, int pos) { return (unsigned)(pos - lo) < len; }
+
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
 
-// X items (16-byte slots = 8 channels of one time step) a thread stages per stage, by tile height
-template <int MT> struct BfXit { static constexpr int v = MT == 4 ? 9 : (MT == 2 ? 7 : 4); };
+// X items (PAIRS of 16-byte slots = 8 channels of two consecutive time steps) a thread stages per stage, by tile height
+template <int MT> struct BfXit { static constexpr int v = MT == 4 ? 6 : (MT == 2 ? 4 : 3); };
+static inline int bf16_xit(int mt) { return mt == 4 ? 6 : (mt == 2 ? 4 : 3); }
+// staged item count of a stage: channel groups x time pairs (one spare pair for an odd first sample), the pairs of a
+// group padded to whole waves
+__host__ __device__ static inline int bf16_pairs64(int pr) { return ((pr + 2) / 2 + 63) & ~63; }
 
 // Stage = NCK chunks of 32 input channels x ALL taps (so a stage carries enough MFMAs -- ~12 tap-chunks --
 // to cover a global-memory round trip).  Weights go global -> LDS directly (global_load_lds, 16 bytes per
@@ -106,60 +115,69 @@ __global__ __launch_bounds__(256, (MT == 4 ? 2 : (MT == 2 ? (NW <= 3 ? 3 : 2) : 
     const int tix0 = seg;
 
     f32x4 acc[MT][NW];
-    float xreg[XIT][8];
-    // X items: a 16-byte LDS slot = 8 channels of one (plane, row).  Item it = tid + i*256 is laid out as
-    // (channel group, position) with the positions of a group padded to a multiple of 64, so the channel
-    // group of an item is uniform across a wave: the 8 row pointers of a load batch are SCALAR values and a
-    // lane contributes only its 32-bit time offset (per-lane 64-bit address arithmetic was the dominant
-    // cost of a stage at bf16 MFMA rates).
+    unsigned xreg[XIT][8];
+    // X items: item it = tid + i*256 is (channel group of 8, time PAIR), the pairs of a group padded to a multiple of 64
+    // so that the channel group of an item is uniform across a wave (the 8 row offsets of a load batch are SCALAR values,
+    // a lane contributes only its 32-bit time offset).  Lane l of a load instruction fetches ONE dword = the bf16 samples
+    // (u, u + 1) of one channel row at an EVEN element index u of the row (rows are 16-byte aligned), so a wave reads 256
+    // contiguous bytes per channel; the 8 dwords of an item are transposed with v_perm_b32 into two 16-byte LDS slots
+    // (8 channels of time u, 8 channels of time u + 1).  `par` = parity of the row element under the tile's first
+    // sample: with par = 1 the first pair starts one sample early and its first element is dropped.
     const int PR = planes * ROWS;
-    const int PR64 = (PR + 63) & ~63;
-    const int nxitems = C8S * PR64;                         // <= XIT*256 (launcher)
-    // tile-invariant per-item state: xfl[i] = (source time relative to the tile start + 64) | channel group << 24
-    // | item-live << 29; xlo[i] = byte offset of the slot in the LDS image.  Per tile: xti[i] = clamped source
-    // time | time-valid << 28.
-    int xfl[XIT], xlo[XIT], xti[XIT];
+    const int PRP64 = bf16_pairs64(PR);
+    const int nxitems = C8S * PRP64;                        // <= XIT*256 (launcher)
+    const int par = (a.off0 - a.shift) & 1;                 // tile-invariant: q0 is even (off0 == off1 for two sources: launcher)
+    // tile-invariant per-item state: xfl[i] = pair index | channel group << 24 | live << 29 | element e inside the image << (30 + e);
+    // xlo0/xlo1[i] = LDS byte offsets of the two slots.  Per tile: xti[i] = clamped row element of the pair | sample e
+    // inside [0, Tin) << (28 + e).
+    unsigned xfl[XIT];
+    int xlo0[XIT], xlo1[XIT], xti[XIT];
 #pragma unroll
     for (int i = 0; i < XIT; ++i) {
         const int it0 = wave * 64 + i * 256;                // wave-uniform
-        const int c8l = it0 / PR64;
-        const int pr = it0 - c8l * PR64 + lane;
-        const bool live = it0 < nxitems && pr < PR;
-        const int pl = (deint && pr >= ROWS) ? 1 : 0;
-        const int row = live ? pr - pl * ROWS : 0;
-        const int tr = (deint ? 2 * row + pl : row) - a.shift + 64;      // >= 0: shift <= 14
-        xfl[i] = tr | (c8l << 24) | ((live ? 1 : 0) << 29);
-        xlo[i] = (pl * ROWS + row) * XPB + c8l * 16;
+        const int c8l = it0 / PRP64;
+        const int pp = it0 - c8l * PRP64 + lane;
+        const bool live = it0 < nxitems;
+        const int tr0 = 2 * pp - par, tr1 = tr0 + 1;        // conv-relative sample index of the two elements
+        const bool in0 = live && tr0 >= 0 && tr0 < PR, in1 = live && tr1 >= 0 && tr1 < PR;
+        xfl[i] = (unsigned)pp | ((unsigned)c8l << 24) | ((live ? 1u : 0u) << 29) | ((in0 ? 1u : 0u) << 30) | ((in1 ? 1u : 0u) << 31);
+        const int r0 = in0 ? tr0 : 0, r1 = in1 ? tr1 : 0;
+        xlo0[i] = (deint ? ((r0 & 1) * ROWS + (r0 >> 1)) : r0) * XPB + c8l * 16;
+        xlo1[i] = (deint ? ((r1 & 1) * ROWS + (r1 >> 1)) : r1) * XPB + c8l * 16;
     }
     // Input rows are fetched with raw buffer loads: resource = this excerpt's tensor, SGPR offset = channel row
-    // (one s_mul per load), VGPR offset = the lane's time index.  A flat load needs ~8 scalar instructions of 64-bit
-    // address arithmetic per row pointer; at bf16 MFMA rates that arithmetic, not the matrix pipe, set the stage time.
-    __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, 0x7FFFFFFE, 0x00020000);
+    // (one s_mul per load), VGPR offset = the lane's byte offset inside the row.  A flat load needs ~8 scalar instructions
+    // of 64-bit address arithmetic per row pointer; at bf16 MFMA rates that arithmetic, not the matrix pipe, set the stage time.
+    const unsigned char* const xsrc0 = reinterpret_cast<const unsigned char*>(a.src0);
+    const unsigned char* const xsrc1 = reinterpret_cast<const unsigned char*>(a.src1);
+    __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)xsrc0, 0, 0x7FFFFFFE, 0x00020000);
     __amdgpu_buffer_rsrc_t rs1 = rs0;
-    const int pb0 = a.pitch0 * 4, pb1 = a.pitch1 * 4;      // row pitches in bytes
+    const int pb0 = a.pitch0 * 2, pb1 = a.pitch1 * 2;      // row pitches in bytes
+    const int umax = (a.pitch0 < a.pitch1 || a.src1 == nullptr ? a.pitch0 : a.pitch1) - 2;   // last pair inside a row (pitches are even)
     auto set_tile = [&](int tix, int& b, int& q0) {
         b = tix / nTT;
         q0 = (tix - b * nTT) * TT;
-        rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src0 + (long long)b * a.bs0 + a.off0), 0, 0x7FFFFFFE, 0x00020000);
+        rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)(xsrc0 + (long long)b * a.bs0 * 2), 0, 0x7FFFFFFE, 0x00020000);
         rs1 = (a.src1 != nullptr)
-                  ? __builtin_amdgcn_make_buffer_rsrc((void*)(a.src1 + (long long)b * a.bs1 + a.off1), 0, 0x7FFFFFFE, 0x00020000)
+                  ? __builtin_amdgcn_make_buffer_rsrc((void*)(xsrc1 + (long long)b * a.bs1 * 2), 0, 0x7FFFFFFE, 0x00020000)
                   : rs0;
-        const int tq = (deint ? 2 * q0 : q0) - 64;
+        const int s0e = a.off0 + (deint ? 2 * q0 : q0) - a.shift - par;      // even row element under conv-relative sample -par
 #pragma unroll
         for (int i = 0; i < XIT; ++i) {
-            const int t = (xfl[i] & 0xFFFFFF) + tq;
-            const int tc = t < 0 ? 0 : (t > a.Tin - 1 ? a.Tin - 1 : t);      // Tin < 2^23 (checked by the launcher)
-            xti[i] = tc | ((t >= 0 && t < a.Tin ? 1 : 0) << 28);
+            const int u = s0e + 2 * (int)(xfl[i] & 0xFFFFFFu);
+            const int t = u - a.off0;                                        // time of element 0 on the source's own axis
+            const int uc = u < 0 ? 0 : (u > umax ? umax : u);                // Tin + off < 2^23 (checked by the launcher)
+            xti[i] = uc | ((t >= 0 && t < a.Tin ? 1 : 0) << 28) | ((t + 1 >= 0 && t + 1 < a.Tin ? 1 : 0) << 29);
         }
     };
 
-    // ---- X: global -> registers, registers -> LDS (bf16, zero fill) ----
+    // ---- X: global -> registers, registers -> LDS ([time][8 channels] slots, zero fill) ----
     auto load_x = [&](int st) {
 #pragma unroll
         for (int i = 0; i < XIT; ++i) {
             if (i * 256 < nxitems) {                         // uniform
-                const int tb = (xti[i] & 0xFFFFFF) * 4;      // byte offset of the lane's time index
-                const int cbase = st * CKW + __builtin_amdgcn_readfirstlane((xfl[i] >> 24) & 15) * 8;     // wave-uniform
+                const int tb = (xti[i] & 0xFFFFFF) * 2;      // byte offset of the pair inside its row
+                const int cbase = st * CKW + __builtin_amdgcn_readfirstlane((int)((xfl[i] >> 24) & 15u)) * 8;     // wave-uniform
                 // a group of 8 channels lies in ONE source (C0 % 8 == 0, checked by the launcher)
                 const bool s1 = cbase >= a.C0;
                 const __amdgpu_buffer_rsrc_t rs = s1 ? rs1 : rs0;
@@ -168,7 +186,7 @@ __global__ __launch_bounds__(256, (MT == 4 ? 2 : (MT == 2 ? (NW <= 3 ? 3 : 2) : 
                 for (int e = 0; e < 8; ++e) {
                     int c = c0 + e;
                     c = c < cmax ? c : cmax;                 // channels past the tensor: any valid row (zero-filled at the store)
-                    xreg[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, tb, c * pb, 0));
+                    xreg[i][e] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, tb, c * pb, 0);
                 }
             }
         }
@@ -177,14 +195,21 @@ __global__ __launch_bounds__(256, (MT == 4 ? 2 : (MT == 2 ? (NW <= 3 ? 3 : 2) : 
         unsigned char* xb = Xs + buf * xbytes;
 #pragma unroll
         for (int i = 0; i < XIT; ++i) {
-            if (i * 256 < nxitems && ((xfl[i] >> 29) & 1)) {
-                const bool tok = (xti[i] >> 28) & 1;
-                const int cbase = st * CKW + __builtin_amdgcn_readfirstlane((xfl[i] >> 24) & 15) * 8;
-                float v[8];
+            if (i * 256 < nxitems && ((xfl[i] >> 29) & 1u)) {
+                const int cbase = st * CKW + __builtin_amdgcn_readfirstlane((int)((xfl[i] >> 24) & 15u)) * 8;
+                unsigned d[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (tok && cbase + e < Ctot) ? xreg[i][e] : 0.f;
-                u32x4 pk = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
-                *reinterpret_cast<u32x4*>(xb + xlo[i]) = pk;
+                for (int e = 0; e < 8; ++e) d[e] = (cbase + e < Ctot) ? xreg[i][e] : 0u;       // (uniform selects)
+                // dword e = samples (u, u + 1) of channel e: low halves -> slot of time u, high halves -> slot of time u + 1
+                const bool t0ok = (xti[i] >> 28) & 1, t1ok = (xti[i] >> 29) & 1;
+                u32x4 lo = {__builtin_amdgcn_perm(d[1], d[0], 0x05040100u), __builtin_amdgcn_perm(d[3], d[2], 0x05040100u),
+                            __builtin_amdgcn_perm(d[5], d[4], 0x05040100u), __builtin_amdgcn_perm(d[7], d[6], 0x05040100u)};
+                u32x4 hi = {__builtin_amdgcn_perm(d[1], d[0], 0x07060302u), __builtin_amdgcn_perm(d[3], d[2], 0x07060302u),
+                            __builtin_amdgcn_perm(d[5], d[4], 0x07060302u), __builtin_amdgcn_perm(d[7], d[6], 0x07060302u)};
+                if (!t0ok) lo = (u32x4){0u, 0u, 0u, 0u};
+                if (!t1ok) hi = (u32x4){0u, 0u, 0u, 0u};
+                if ((xfl[i] >> 30) & 1u) *reinterpret_cast<u32x4*>(xb + xlo0[i]) = lo;
+                if ((xfl[i] >> 31) & 1u) *reinterpret_cast<u32x4*>(xb + xlo1[i]) = hi;
             }
         }
     };
@@ -250,7 +275,8 @@ __global__ __launch_bounds__(256, (MT == 4 ? 2 : (MT == 2 ? (NW <= 3 ? 3 : 2) : 
         }
     };
 
-    // ---- epilogue of one tile (fp32; same arithmetic as the exact-fp32 kernel's).  Every launch argument it needs
+    // ---- epilogue of one tile (fp32 arithmetic, the exact-fp32 kernel's; OB: destinations, masks and the decimated copy
+    // hold bf16 -- rounded to nearest even on the store, 4 values per 8-byte store).  Every launch argument it needs
     // is read into a local first: selecting between `a.dst0` and `a.dst1` per lane otherwise compiles to a VECTOR load
     // of the kernel-argument segment followed by s_waitcnt vmcnt(0) -- which also drains the input prefetch of the next
     // tile and serialises the whole pipeline (measured: phases became exactly additive) ----
@@ -264,6 +290,7 @@ __global__ __launch_bounds__(256, (MT == 4 ? 2 : (MT == 2 ? (NW <= 3 ? 3 : 2) : 
     const long long e_obs0 = a.obs0, e_obs1 = a.obs1, e_decbs = a.decbs;
     const int e_op0 = a.opitch0, e_op1 = a.opitch1, e_oo0 = a.ooff0, e_oo1 = a.ooff1, e_N = a.N, e_N0 = a.N0,
               e_Tout = a.Tout, e_os = a.ostride, e_decp = a.decpitch;
+    const int e_acc_lo = a.acc_lo; const unsigned e_acc_len = a.acc_len;
     float e_bv[NW];                                         // this lane's bias values, loaded once (a load inside the
 #pragma unroll                                              // tile loop would wait on vmcnt(0) and drain the input prefetch)
     for (int n = 0; n < NW; ++n) {
@@ -271,9 +298,13 @@ __global__ __launch_bounds__(256, (MT == 4 ? 2 : (MT == 2 ? (NW <= 3 ? 3 : 2) : 
         e_bv[n] = (e_bias != nullptr && ncol < e_N) ? e_bias[ncol] : 0.f;
     }
     const int e_Tlim = a.Tlim;
-    auto epilogue = [&](int b, int q0) {
+    auto epilogue = [&](int b, int q0, auto obtag) {
+        constexpr bool OB = decltype(obtag)::value;
+        using ET = std::conditional_t<OB, bf16_t, float>;
         if (phase2) {
             if constexpr ((NW % 2) == 0) {
+                ET* const dst = reinterpret_cast<ET*>(e_dst0);
+                const ET* const msk = reinterpret_cast<const ET*>(e_msk0);
 #pragma unroll
                 for (int n = 0; n < NW / 2; ++n) {
                     const int ncol = n0 + n * 16 + li;
@@ -288,9 +319,8 @@ __global__ __launch_bounds__(256, (MT == 4 ? 2 : (MT == 2 ? (NW <= 3 ? 3 : 2) : 
                         for (int r = 0; r < 4; ++r) { v[2 * r] = acc[m][n][r]; v[2 * r + 1] = acc[m][NW / 2 + n][r]; }
                         if (vec && t0 + 7 < e_Tlim) {
                             const long long idx = rowbase + t0;
-                            if (e_msk0 != nullptr) {
-                                const f32x4 m0 = *reinterpret_cast<const f32x4*>(&e_msk0[idx]);
-                                const f32x4 m1 = *reinterpret_cast<const f32x4*>(&e_msk0[idx + 4]);
+                            if (msk != nullptr) {
+                                const f32x4 m0 = ld4<ET>(msk, idx), m1 = ld4<ET>(msk, idx + 4);
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
                                     v[r] *= (m0[r] > 0.f) ? 1.f : 0.2f;
@@ -298,22 +328,24 @@ __global__ __launch_bounds__(256, (MT == 4 ? 2 : (MT == 2 ? (NW <= 3 ? 3 : 2) : 
                                 }
                             }
                             if (accum) {
-                                const f32x4 o0 = *reinterpret_cast<const f32x4*>(&e_dst0[idx]);
-                                const f32x4 o1 = *reinterpret_cast<const f32x4*>(&e_dst0[idx + 4]);
+                                const f32x4 o0 = ld4<ET>(dst, idx), o1 = ld4<ET>(dst, idx + 4);
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) { v[r] += o0[r]; v[4 + r] += o1[r]; }
+                                for (int r = 0; r < 4; ++r) {
+                                    if (conv_acc_pos(e_acc_lo, e_acc_len, e_oo0 + t0 + r)) v[r] += o0[r];
+                                    if (conv_acc_pos(e_acc_lo, e_acc_len, e_oo0 + t0 + 4 + r)) v[4 + r] += o1[r];
+                                }
                             }
-                            *reinterpret_cast<f32x4*>(&e_dst0[idx]) = (f32x4){v[0], v[1], v[2], v[3]};
-                            *reinterpret_cast<f32x4*>(&e_dst0[idx + 4]) = (f32x4){v[4], v[5], v[6], v[7]};
+                            st4<ET>(dst, idx, (f32x4){v[0], v[1], v[2], v[3]});
+                            st4<ET>(dst, idx + 4, (f32x4){v[4], v[5], v[6], v[7]});
                         } else {
 #pragma unroll
                             for (int r = 0; r < 8; ++r) {
                                 if (t0 + r < e_Tlim) {
                                     const long long idx = rowbase + t0 + r;
                                     float x = v[r];
-                                    if (e_msk0 != nullptr) x *= (e_msk0[idx] > 0.f) ? 1.f : 0.2f;
-                                    if (accum) x += e_dst0[idx];
-                                    e_dst0[idx] = x;
+                                    if (msk != nullptr) x *= (ld1<ET>(msk, idx) > 0.f) ? 1.f : 0.2f;
+                                    if (accum && conv_acc_pos(e_acc_lo, e_acc_len, e_oo0 + t0 + r)) x += ld1<ET>(dst, idx);
+                                    st1<ET>(dst, idx, x);
                                 }
                             }
                         }
@@ -328,11 +360,12 @@ __global__ __launch_bounds__(256, (MT == 4 ? 2 : (MT == 2 ? (NW <= 3 ? 3 : 2) : 
             if (ncol >= e_N) continue;
             const float bvv = e_bv[n];
             const bool first = ncol < e_N0;
-            float* const dst = first ? e_dst0 : e_dst1;
-            const float* const msk = first ? e_msk0 : e_msk1;
+            ET* const dst = reinterpret_cast<ET*>(first ? e_dst0 : e_dst1);
+            const ET* const msk = reinterpret_cast<const ET*>(first ? e_msk0 : e_msk1);
             const long long rowbase = first ? (long long)b * e_obs0 + (long long)ncol * e_op0 + e_oo0
                                             : (long long)b * e_obs1 + (long long)(ncol - e_N0) * e_op1 + e_oo1;
-            float* decrow = (e_dec != nullptr && first) ? e_dec + (long long)b * e_decbs + (long long)ncol * e_decp : nullptr;
+            const int oo = first ? e_oo0 : e_oo1;
+            ET* decrow = (e_dec != nullptr && first) ? reinterpret_cast<ET*>(e_dec) + (long long)b * e_decbs + (long long)ncol * e_decp : nullptr;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const int q = q0 + wt0 + m * 16 + lg * 4;
@@ -345,15 +378,24 @@ __global__ __launch_bounds__(256, (MT == 4 ? 2 : (MT == 2 ? (NW <= 3 ? 3 : 2) : 
                     }
                     const long long idx = rowbase + q;
                     if (msk != nullptr) {
-                        const f32x4 mk = *reinterpret_cast<const f32x4*>(&msk[idx]);
+                        const f32x4 mk = ld4<ET>(msk, idx);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] *= (mk[r] > 0.f) ? 1.f : 0.2f;
                     }
-                    if (accum) v += *reinterpret_cast<const f32x4*>(&dst[idx]);
-                    *reinterpret_cast<f32x4*>(&dst[idx]) = v;
+                    if (accum) {
+                        const f32x4 o = ld4<ET>(dst, idx);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (conv_acc_pos(e_acc_lo, e_acc_len, oo + q + r)) v[r] += o[r];
+                    }
+                    st4<ET>(dst, idx, v);
                     if (decrow != nullptr) {
-                        decrow[q >> 1] = v[0];
-                        decrow[(q >> 1) + 1] = v[2];
+                        if constexpr (OB) {
+                            *reinterpret_cast<unsigned*>(decrow + (q >> 1)) = bf_pack2(v[0], v[2]);
+                        } else {
+                            decrow[q >> 1] = v[0];
+                            decrow[(q >> 1) + 1] = v[2];
+                        }
                     }
                 } else {
 #pragma unroll
@@ -362,10 +404,10 @@ __global__ __launch_bounds__(256, (MT == 4 ? 2 : (MT == 2 ? (NW <= 3 ? 3 : 2) : 
                             float v = acc[m][n][r] + bvv;
                             if (lrelu) v = fmaxf(0.2f * v, v);
                             const long long idx = rowbase + (long long)(q + r) * e_os;
-                            if (msk != nullptr) v *= (msk[idx] > 0.f) ? 1.f : 0.2f;
-                            if (accum) v += dst[idx];
-                            dst[idx] = v;
-                            if (decrow != nullptr && ((q + r) & 1) == 0) decrow[(q + r) >> 1] = v;
+                            if (msk != nullptr) v *= (ld1<ET>(msk, idx) > 0.f) ? 1.f : 0.2f;
+                            if (accum && conv_acc_pos(e_acc_lo, e_acc_len, oo + (q + r) * e_os)) v += ld1<ET>(dst, idx);
+                            st1<ET>(dst, idx, v);
+                            if (decrow != nullptr && ((q + r) & 1) == 0) st1<ET>(decrow, (q + r) >> 1, v);
                         }
                     }
                 }
@@ -405,7 +447,10 @@ __global__ __launch_bounds__(256, (MT == 4 ? 2 : (MT == 2 ? (NW <= 3 ? 3 : 2) : 
             __syncthreads();
         }
     }
-    if (!ab_noepi) epilogue(b, q0);
+    if (!ab_noepi) {
+        if (a.obf) epilogue(b, q0, std::true_type{});
+        else epilogue(b, q0, std::false_type{});
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -413,12 +458,15 @@ __global__ __launch_bounds__(256, (MT == 4 ? 2 : (MT == 2 ? (NW <= 3 ? 3 : 2) : 
 // ---------------------------------------------------------------------------------------
 bool conv_bf16_supported(const ConvArgs& a) {
     if ((a.flags & F_PHASE2) && !(a.ostride == 1 && a.dst1 == nullptr && a.loader == LOADER_DIRECT)) return false;
-    if (a.C0 + a.C1 < 8) return false;                    // the 1-/2-channel audio input stays on the exact-fp32 kernel
+    if (a.C0 + a.C1 < 8) return false;                    // the 1-/2-channel audio input has its own kernel (first_conv_kernel)
     if (a.KW < 1 || a.KW > WUN_BF_KMAX) return false;
-    if (a.Tin >= (1 << 23)) return false;
+    if ((long long)a.Tin + a.off0 >= (1 << 23) || (long long)a.Tin + a.off1 >= (1 << 23) || a.off0 < 0) return false;
     if (a.C1 > 0 && (a.C0 & 7) != 0) return false;         // an 8-channel group must not straddle the two sources
+    if (a.C1 > 0 && a.off0 != a.off1) return false;        // one time-pair alignment for both sources (always 0 / 0 in the plan)
+    if ((a.pitch0 & 1) != 0 || (a.bs0 & 1) != 0 || (a.C1 > 0 && ((a.pitch1 & 1) != 0 || (a.bs1 & 1) != 0))) return false;   // dword pairs
+    if (a.pitch0 < 2 || (a.C1 > 0 && a.pitch1 < 2)) return false;
     // the excerpt's tensor is addressed with 32-bit byte offsets
-    if ((long long)a.C0 * a.pitch0 * 4 >= (1ll << 31) || (long long)a.C1 * a.pitch1 * 4 >= (1ll << 31)) return false;
+    if ((long long)a.C0 * a.pitch0 * 2 >= (1ll << 31) || (long long)a.C1 * a.pitch1 * 2 >= (1ll << 31)) return false;
     return true;
 }
 
@@ -446,7 +494,7 @@ static int bf16_pick_nck(const ConvArgs& a, int TT, int NT, int xit) {
     const int planes = a.loader == LOADER_DEINT ? 2 : 1;
     const int maxck = (a.C0 + a.C1 + 31) / 32;
     auto fits = [&](int nck) {
-        return ((planes * bf16_rows(a, TT) + 63) & ~63) * 4 * nck <= xit * 256 && bf16_lds(a, TT, NT, nck) <= 160 * 1024;
+        return bf16_pairs64(planes * bf16_rows(a, TT)) * 4 * nck <= xit * 256 && bf16_lds(a, TT, NT, nck) <= 160 * 1024;
     };
     // all input channels in one stage -> weights-stationary schedule
     if (maxck <= 3 && fits(maxck)) return maxck;
@@ -500,7 +548,7 @@ static hipError_t conv_bf16_launch_t(ConvArgs a, hipStream_t s, int nck_force = 
     const bool deint = a.loader == LOADER_DEINT;
     const int planes = deint ? 2 : 1;
     const size_t lds = bf16_lds(a, TT, NT, NCK);
-    if (lds > 160 * 1024 || ((planes * ROWS + 63) & ~63) * 4 * NCK > BfXit<MT>::v * 256) return hipErrorInvalidValue;
+    if (lds > 160 * 1024 || bf16_pairs64(planes * ROWS) * 4 * NCK > BfXit<MT>::v * 256) return hipErrorInvalidValue;
     const bool phase2 = (a.flags & F_PHASE2) != 0;
     if (phase2 && ((NW % 2) != 0 || deint)) return hipErrorInvalidValue;
     const int nTT = (a.Tout + TT - 1) / TT, nNT = phase2 ? (a.N + NT / 2 - 1) / (NT / 2) : (a.N + NT - 1) / NT;
@@ -531,8 +579,7 @@ bool conv_bf16_choice_ok(const ConvArgs& a, int variant) {
     if (TT > 64 && TT >= 2 * a.Tout) return false;                     // mostly padding in time
     if (nck > (a.C0 + a.C1 + 31) / 32) return false;
     const int planes = a.loader == LOADER_DEINT ? 2 : 1;
-    const int xit = mt == 4 ? 9 : (mt == 2 ? 7 : 4);
-    if (((planes * bf16_rows(a, TT) + 63) & ~63) * 4 * nck > xit * 256) return false;
+    if (bf16_pairs64(planes * bf16_rows(a, TT)) * 4 * nck > bf16_xit(mt) * 256) return false;
     return bf16_lds(a, TT, NT, nck) <= 160 * 1024;
 }
 int conv_bf16_list_candidates(const ConvArgs& a, ConvChoice* out, int maxn) {
@@ -545,12 +592,14 @@ int conv_bf16_list_candidates(const ConvArgs& a, ConvChoice* out, int maxn) {
 // a.W must point at the packed bf16 image of the layer's weights (pack_bf16_kernel), a.wb_c8p / a.wb_npad set
 hipError_t launch_conv_bf16(const ConvArgs& a_in, hipStream_t s) {
     ConvArgs a = a_in;
-    if (!conv_bf16_supported(a) || a.wb_c8p <= 0 || a.wb_npad <= 0 || !al16(a.W)) return hipErrorInvalidValue;
+    if (!a.xbf || !conv_bf16_supported(a) || a.wb_c8p <= 0 || a.wb_npad <= 0 || !al16(a.W)) return hipErrorInvalidValue;
+    if (!al16(a.src0) || (a.src1 != nullptr && !al16(a.src1))) return hipErrorInvalidValue;      // dword pairs at even row elements
+    if (a.acc_len == 0) { a.acc_lo = 0; a.acc_len = 0x7FFFFFFFu; }                               // F_ACCUM over the whole row (default)
     bool vec = a.ostride == 1 && al16(a.dst0) && (a.obs0 & 3) == 0 && (a.opitch0 & 3) == 0 && (a.ooff0 & 3) == 0;
     if (a.dst1 != nullptr) vec = vec && al16(a.dst1) && (a.obs1 & 3) == 0 && (a.opitch1 & 3) == 0 && (a.ooff1 & 3) == 0;
     if (a.msk0 != nullptr) vec = vec && al16(a.msk0);
     if (a.msk1 != nullptr) vec = vec && al16(a.msk1);
-    if (a.dec != nullptr) vec = vec && (a.decpitch & 1) == 0 && (a.decbs & 1) == 0;
+    if (a.dec != nullptr) vec = vec && (a.decpitch & 1) == 0 && (a.decbs & 1) == 0 && al16(a.dec);
     if (vec) a.flags |= F_VEC4;
     if (const char* e = getenv("WUN_BF_ABL")) a.flags |= atoi(e) << 16;      // diagnostic: skip phases of the kernel
     // autotuned choice (ConvChoice.variant = kBf16VariantBase + tile code; checked by conv_bf16_choice_ok)
@@ -585,9 +634,9 @@ hipError_t launch_conv_bf16(const ConvArgs& a_in, hipStream_t s) {
     static const int lds_cap = getenv("WUN_BF16_LDS_CAP") ? atoi(getenv("WUN_BF16_LDS_CAP")) : 80;
     {
         int m2 = mt;
-        while (m2 > 1 && bf16_lds(a, 64 * m2, bestnw * 16, bf16_pick_nck(a, 64 * m2, bestnw * 16, m2 == 4 ? 9 : (m2 == 2 ? 7 : 4))) >
+        while (m2 > 1 && bf16_lds(a, 64 * m2, bestnw * 16, bf16_pick_nck(a, 64 * m2, bestnw * 16, bf16_xit(m2))) >
                              (size_t)lds_cap * 1024) m2 >>= 1;
-        if (bf16_lds(a, 64 * m2, bestnw * 16, bf16_pick_nck(a, 64 * m2, bestnw * 16, m2 == 4 ? 9 : (m2 == 2 ? 7 : 4))) <= (size_t)lds_cap * 1024)
+        if (bf16_lds(a, 64 * m2, bestnw * 16, bf16_pick_nck(a, 64 * m2, bestnw * 16, bf16_xit(m2))) <= (size_t)lds_cap * 1024)
             mt = m2;
     }
 #define WUN_BF(M, N) if (mt == M && bestnw == N) return conv_bf16_launch_t<M, N>(a, s);
@@ -596,6 +645,136 @@ hipError_t launch_conv_bf16(const ConvArgs& a_in, hipStream_t s) {
     WUN_BF(1, 4) WUN_BF(1, 3) WUN_BF(1, 2)
 #undef WUN_BF
     return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------
+// The audio-input conv of the bf16 mode (UnetAudioSeparator.py:98 at i = 0: 1 or 2 input channels): fp32 audio in,
+// bf16 activations out.  No dense channel x channel face (Cin <= 2), so it runs as a direct conv on the vector pipe,
+// bound by writing the 24 .. 48 output rows: a thread owns 4 consecutive output positions of EVERY output channel -- its
+// input window of 3 SI + K samples per channel sits in registers, the weights of one output channel are uniform
+// (scalar loads), 4 K Cin FMAs per output channel, one 8-byte (bf16) / 16-byte (fp32) store per channel row: a wave
+// writes 512 contiguous bytes per row.  Same epilogue as the MFMA convs: bias, LeakyReLU, optional compact copy of the
+// even positions (the [:, ::2, :] of :100 in same-padding mode).  ConvArgs: src0 fp32 (xbf = 0), C1 = 0, W fp32 in TF
+// layout [K][Cin][Cout], dst0 / dec bf16 (obf = 1) or fp32; loader DIRECT = stride 1, DEINT = stride 2.
+// ---------------------------------------------------------------------------------------
+template <int SI, int CIN, bool OB>
+__global__ __launch_bounds__(256) void first_conv_kernel(ConvArgs a) {
+    using ET = std::conditional_t<OB, bf16_t, float>;
+    constexpr int XW = 3 * SI + WUN_BF_KMAX;                // window for 4 positions, K <= 15
+    const int b = blockIdx.y;
+    const int q = ((int)blockIdx.x * 256 + (int)threadIdx.x) * 4;
+    if (q >= a.Tout) return;
+    const int K = a.KW;
+    const int xw = 3 * SI + K;
+    float xv[CIN][XW];
+    const int t0 = q * SI - a.shift;
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) {
+        const float* xr = a.src0 + (long long)b * a.bs0 + (long long)c * a.pitch0 + a.off0;
+#pragma unroll
+        for (int i = 0; i < XW; ++i) {
+            const int t = t0 + i;
+            const int tc = t < 0 ? 0 : (t > a.Tin - 1 ? a.Tin - 1 : t);
+            const float v = xr[tc];
+            xv[c][i] = (i < xw && t >= 0 && t < a.Tin) ? v : 0.f;
+        }
+    }
+    const float* __restrict__ W = a.W;
+    const float* __restrict__ bias = a.bias;
+    const bool lrelu = (a.flags & F_LRELU) != 0;
+    const bool full = q + 3 < a.Tout;
+    ET* const dst = reinterpret_cast<ET*>(a.dst0) + (long long)b * a.obs0 + a.ooff0;
+    ET* const dec = a.dec != nullptr ? reinterpret_cast<ET*>(a.dec) + (long long)b * a.decbs : nullptr;
+    for (int n = 0; n < a.N; ++n) {
+        float acc[4];
+        const float bv = bias != nullptr ? bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = bv;
+#pragma unroll
+        for (int k = 0; k < WUN_BF_KMAX; ++k) {
+            if (k < K) {
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) {
+                    const float w = W[((long long)k * CIN + c) * a.N + n];      // uniform: scalar load
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = fmaf(xv[c][r * SI + k], w, acc[r]);
+                }
+            }
+        }
+        if (lrelu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = fmaxf(0.2f * acc[r], acc[r]);
+        }
+        const long long row = (long long)n * a.opitch0;
+        if (full) {
+            st4<ET>(dst, row + q, (f32x4){acc[0], acc[1], acc[2], acc[3]});
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (q + r < a.Tout) st1<ET>(dst, row + q + r, acc[r]);
+        }
+        if (dec != nullptr) {
+            ET* dr = dec + (long long)n * a.decpitch;
+            st1<ET>(dr, q >> 1, acc[0]);
+            if (q + 2 < a.Tout) st1<ET>(dr, (q >> 1) + 1, acc[2]);
+        }
+    }
+}
+
+bool first_conv_supported(const ConvArgs& a) {
+    return a.C1 == 0 && (a.C0 == 1 || a.C0 == 2) && a.KW >= 1 && a.KW <= WUN_BF_KMAX && !a.xbf && a.ostride == 1 &&
+           a.dst1 == nullptr && a.msk0 == nullptr && (a.flags & (F_ACCUM | F_PHASE2)) == 0 && a.N0 == a.N && a.B <= 65535 &&
+           (a.opitch0 & 3) == 0 && (a.obs0 & 3) == 0 && (a.ooff0 & 3) == 0 && al16(a.dst0);
+}
+
+hipError_t launch_first_conv(const ConvArgs& a, hipStream_t s) {
+    if (!first_conv_supported(a)) return hipErrorInvalidValue;
+    if (a.Tout <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((a.Tout + 1023) / 1024), (unsigned)a.B);
+    char tag[128];
+    snprintf(tag, sizeof(tag), "C=%d N=%d T=%d K=%d ld=%d B=%d", a.C0, a.N, a.Tout, a.KW, a.loader, a.B);
+    // (bandwidth-bound: the output rows written once, the audio read once)
+    prof_scope_begin("first_conv_kernel", conv_flops(a), s, tag,
+                     (double)a.B * a.Tout * ((a.obf ? 2.0 : 4.0) * a.N * (a.dec != nullptr ? 1.5 : 1.0) + 4.0 * a.C0 * (a.loader == LOADER_DEINT ? 2 : 1)));
+#define WUN_FC(SI, CI) \
+    if (a.obf) hipLaunchKernelGGL((first_conv_kernel<SI, CI, true>), grid, dim3(256), 0, s, a); \
+    else hipLaunchKernelGGL((first_conv_kernel<SI, CI, false>), grid, dim3(256), 0, s, a);
+    if (a.loader == LOADER_DEINT) { if (a.C0 == 1) { WUN_FC(2, 1) } else { WUN_FC(2, 2) } }
+    else { if (a.C0 == 1) { WUN_FC(1, 1) } else { WUN_FC(1, 2) } }
+#undef WUN_FC
+    prof_scope_end(s);
+    return hipGetLastError();
+}
+
+// fp32 rows -> bf16 rows (nearest even), re-pitched: dst[r][t] = bf16(src[r][t]), t < T.  Used by the single-operator entry
+// points (their callers hand over fp32 tensors) -- the plan never converts: its tensors are born bf16.
+__global__ __launch_bounds__(256) void cast_rows_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int T,
+                                                            long long spitch, long long dpitch) {
+    const long long r = blockIdx.y;
+    const int t = ((int)blockIdx.x * 256 + (int)threadIdx.x) * 4;
+    if (t >= T) return;
+    const float* sp = src + r * spitch + t;
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = t + k < T ? sp[k] : 0.f;
+    bf16_t* dp = dst + r * dpitch + t;
+    if (t + 3 < dpitch && ((dpitch & 3) == 0)) {
+        st4<bf16_t>(dp, 0, (f32x4){v[0], v[1], v[2], v[3]});
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (t + k < T) st1<bf16_t>(dp, k, v[k]);
+    }
+}
+
+hipError_t launch_cast_rows_bf16(const float* src, void* dst, long long rows, int T, long long spitch, long long dpitch, hipStream_t s) {
+    if (rows <= 0 || T <= 0) return hipSuccess;
+    for (long long r0 = 0; r0 < rows; r0 += 65535) {
+        const long long nr = rows - r0 < 65535 ? rows - r0 : 65535;
+        hipLaunchKernelGGL(cast_rows_bf16_kernel, dim3((unsigned)((T + 1023) / 1024), (unsigned)nr), dim3(256), 0, s,
+                           src + r0 * spitch, reinterpret_cast<bf16_t*>(dst) + r0 * dpitch, T, spitch, dpitch);
+    }
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------

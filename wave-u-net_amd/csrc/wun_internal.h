@@ -66,6 +66,10 @@ struct ConvArgs {
     // storing d_up, the split-K epilogue writes ubw_dz[b][c][i] = (d_up[2i] + wa d_up[2i+1] + 1/2 d_up[2i-1]) *
     // LeakyReLU'(ubw_x[b][c][i]) -- the arithmetic of upsample_bwd_vec_kernel; rows of ubw_dz / ubw_x share one geometry.
     float* ubw_dz; const float* ubw_x; long long ubw_bs; int ubw_pitch; int ubw_n;
+    // bf16 storage (compute_dtype = 1, section "bf16 activations in HBM" of DESIGN.md): xbf -- src0 / src1 point at bf16
+    // elements; obf -- dst0 / dst1 / msk0 / msk1 / dec point at bf16 elements.  All pitches, batch strides and offsets of a
+    // tensor are in ITS elements.  Only the bf16 kernels (wun_bf16.hip) read these.
+    int xbf, obf;
 };
 // Conv tile variants [42, 56) were the register-window conv tiles of round 4 (per launch on par with the DMA-staged
 // conv_mfma_kernel tiles, 0.5 % slower per step; removed in round 5).  The index range stays RETIRED -- never a legal
@@ -97,6 +101,7 @@ struct WgradArgs {
     int force_mtw, force_nw;   // autotuner: geometry overrides (0 = heuristic)
     int bf16;        // speed mode: operands rounded to bf16 in LDS, v_mfma_f32_16x16x32_bf16 (wun_wgrad_bf16.hip)
     int win;         // exact fp32, register-window form (wun_wgrad_win.hip) instead of the LDS-tiled wgrad_mfma_kernel
+    int sbf;         // bf16 kernel: src0 / src1 AND dz point at bf16 elements (pitches / strides / offsets in elements)
 };
 
 // tile geometry of an exact-fp32 weight-gradient launch
@@ -131,6 +136,7 @@ struct NarrowWgradArgs {
     int N, Nper, Tq, B;
     float* partial;      // [splits][(KW*Ctot + 1) * N]
     int split_base, nsplit, units_per_split, nQT;
+    int et;              // element types: bit 0 src0, bit 1 src1, bit 2 dz stored as bf16 (geometry in elements)
 };
 
 struct ConvChoice { int variant; int ksplit; };
@@ -145,6 +151,7 @@ struct UpsampleArgs {
     float* y; long long ybs; int ypitch; int tup;          // [B][C][tup]
     const float* w;                                        // interp weights [C] or null (linear)
     int C; int B; int context;
+    int bf;                                                // x and y hold bf16 elements
 };
 
 struct UpsampleBwdArgs {
@@ -153,6 +160,7 @@ struct UpsampleBwdArgs {
     float* dz;                                             // out: dL/d(pre-activation of x), geometry of x
     const float* w; float* dw;                             // interp weights / their gradient (or null)
     int C; int B; int context;
+    int bf;                                                // dy, x and dz hold bf16 elements
 };
 
 struct HeadArgs {
@@ -169,6 +177,7 @@ struct HeadArgs {
     float* dzfeat;                                         // geometry of feat
     float* loss_partial;                                   // [gridDim.x]
     float gscale;                                          // 2 / (S*B*Tout*C)
+    int featbf;                                            // feat and dzfeat hold bf16 elements (fbs / fpitch in elements)
 };
 
 // bf16 mode: one conv's weights, fp32 [KW][C][N] (from the parameter arena or a transposed copy in
@@ -187,6 +196,37 @@ struct WtDesc {      // mode 0: dst[j][n][c] = src[k_last - j*k_step][c][n]
     int J, C, N, k_last, k_step;
     int mode;
 };
+
+// ---- bf16 storage helpers (device): a tensor element type ET is float or bf16_t; values are converted to float on load
+// and rounded to nearest-even (v_cvt_pk_bf16_f32) on store.  ET = float compiles to the plain accesses.
+typedef unsigned short bf16_t;
+typedef float wun_f32x4 __attribute__((ext_vector_type(4)));
+typedef float wun_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned wun_u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 wun_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bf_pack2(float lo, float hi) {       // two fp32 -> packed bf16 pair (RNE)
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((wun_f32x2){lo, hi}, wun_bf16x2));
+}
+__device__ __forceinline__ float bf_lo(unsigned v) { return __builtin_bit_cast(float, v << 16); }
+__device__ __forceinline__ float bf_hi(unsigned v) { return __builtin_bit_cast(float, v & 0xFFFF0000u); }
+template <typename ET> __device__ __forceinline__ float ld1(const ET* p, long long i);
+template <> __device__ __forceinline__ float ld1<float>(const float* p, long long i) { return p[i]; }
+template <> __device__ __forceinline__ float ld1<bf16_t>(const bf16_t* p, long long i) { return __builtin_bit_cast(float, (unsigned)p[i] << 16); }
+template <typename ET> __device__ __forceinline__ void st1(ET* p, long long i, float v);
+template <> __device__ __forceinline__ void st1<float>(float* p, long long i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void st1<bf16_t>(bf16_t* p, long long i, float v) { p[i] = (bf16_t)(bf_pack2(v, 0.f) & 0xFFFFu); }
+// four consecutive elements; p + i must be aligned to 4 elements (16 bytes fp32 / 8 bytes bf16)
+template <typename ET> __device__ __forceinline__ wun_f32x4 ld4(const ET* p, long long i);
+template <> __device__ __forceinline__ wun_f32x4 ld4<float>(const float* p, long long i) { return *reinterpret_cast<const wun_f32x4*>(p + i); }
+template <> __device__ __forceinline__ wun_f32x4 ld4<bf16_t>(const bf16_t* p, long long i) {
+    const wun_u32x2 v = *reinterpret_cast<const wun_u32x2*>(p + i);
+    return (wun_f32x4){bf_lo(v[0]), bf_hi(v[0]), bf_lo(v[1]), bf_hi(v[1])};
+}
+template <typename ET> __device__ __forceinline__ void st4(ET* p, long long i, wun_f32x4 v);
+template <> __device__ __forceinline__ void st4<float>(float* p, long long i, wun_f32x4 v) { *reinterpret_cast<wun_f32x4*>(p + i) = v; }
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, long long i, wun_f32x4 v) {
+    *reinterpret_cast<wun_u32x2*>(p + i) = (wun_u32x2){bf_pack2(v[0], v[1]), bf_pack2(v[2], v[3])};
+}
 
 // ---- launchers (wun_kernels.hip) ---------------------------------------------------
 size_t conv_lds_bytes(const ConvArgs& a, int variant);
@@ -245,6 +285,9 @@ static inline int bf16_image_groups(int C) {
 bool conv_bf16_supported(const ConvArgs& a);
 bool conv_bf16_preferred(const ConvArgs& a, long long min_rows);
 hipError_t launch_conv_bf16(const ConvArgs& a, hipStream_t s);
+bool first_conv_supported(const ConvArgs& a);
+hipError_t launch_first_conv(const ConvArgs& a, hipStream_t s);                 // audio-input conv of the bf16 mode
+hipError_t launch_cast_rows_bf16(const float* src, void* dst, long long rows, int T, long long spitch, long long dpitch, hipStream_t s);
 hipError_t launch_pack_bf16(const float* params, float* ws, const PackDesc* dev_descs, int ndesc, long long max_items,
                             hipStream_t s);
 hipError_t launch_mfma_bf16_probe(const float* a, const float* b, float* d, hipStream_t s);
