@@ -119,7 +119,8 @@ int wun_plan_tensor(const wun_plan* plan, int64_t index, wun_tensor_info* info);
  * the backward pass reads its LeakyReLU derivatives from (Utils.py:79-80).  Used by the parity tests to pin the float64
  * oracle's LeakyReLU branch decisions to the ones the kernels took (a pre-activation within fp32 rounding of 0 otherwise
  * decides a 1-vs-0.2 factor differently in the two precisions), and by tools/ws_diff.py.  Every tensor is NCW:
- * element (b, c, j) at workspace[offset + b*batch_stride + c*pitch + j] and holds the POST-activation output of conv
+ * element (b, c, j) is element b*batch_stride + c*pitch + j of the array that starts `offset` floats into the workspace
+ * (float32 or bfloat16 elements: elem_bytes) and holds the POST-activation output of conv
  * position t0 + j*tstep of its layer (UnetAudioSeparator.py:98-100,102,123):
  *   kind 0, index i : decimated stream of down level i  (t0 = 0, tstep = 2: the [:, ::2, :] of :100)
  *   kind 1, index i : skip window of down level i       (context: the centre crop Utils.crop takes, t0 = crop start;
@@ -128,9 +129,11 @@ int wun_plan_tensor(const wun_plan* plan, int64_t index, wun_tensor_info* info);
  *   kind 3, index j : output of up conv j (:123)
  * All fields are int64.  WUN_ERR_INVALID for an unknown kind / index. */
 typedef struct wun_activation_info {
-    int64_t offset, batch_stride, pitch;    /* in floats */
+    int64_t offset;                         /* of the tensor, in FLOATS from the workspace base */
+    int64_t batch_stride, pitch;            /* in ELEMENTS of the tensor */
     int64_t channels, frames;               /* frames = valid positions j per row */
     int64_t t0, tstep;
+    int64_t elem_bytes;                     /* 4 = float32; 2 = bfloat16 (compute_dtype = 1: activations live in HBM as bf16) */
 } wun_activation_info;
 int wun_plan_activation(const wun_plan* plan, int32_t kind, int32_t index, wun_activation_info* info);
 

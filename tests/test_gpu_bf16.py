@@ -1,13 +1,16 @@
-"""bf16-MFMA speed mode (wun_config.compute_dtype = 1; BASELINE.json configs[2], [4]) on an MI355X.
+"""bf16 mode (wun_config.compute_dtype = 1; BASELINE.json configs[2], [4]) on an MI355X.
 
-What the mode changes: the operands of every conv / input-gradient MFMA (Cin >= 8) are rounded to bf16
-(nearest-even) and multiplied on v_mfma_f32_16x16x32_bf16 with fp32 accumulation; HBM tensors, master
-weights, Adam, the weight gradients, the 1-/2-channel input conv and the output head stay fp32.
-Checks: (1) the MFMA lane layout; (2) the bf16 conv operator against a float64 conv of the
-bf16-ROUNDED operands -- products of bf16 numbers are exact in fp32, so this holds to fp32
-accumulation error (OP_TOL), i.e. the kernel is exact up to the stated operand rounding; (3) whole
-training steps against the float64 oracle (un-rounded) within the mode's own, looser tolerances
-(BF16_*), stated below and logged like the fp32 ones."""
+What the mode is (round 5): every activation and activation-gradient tensor lives in HBM as bf16 -- written by the
+epilogue that produces it (fp32 accumulate, one round-to-nearest-even on the store), read as it is by the bf16 MFMA convs
+(v_mfma_f32_16x16x32_bf16), the bf16 weight-gradient kernel and the element-type aware elementwise / head kernels; master
+weights, weight gradients, Adam and the audio itself stay fp32; the 1-/2-channel audio-input conv is a direct fp32 conv
+that stores bf16.  Plans whose layer widths are not multiples of 8 (num_initial_filters % 8 != 0) run the exact-fp32 plan.
+Checks: (1) the MFMA lane layout; (2) the bf16 conv / input-gradient / weight-gradient operators against a float64
+computation of the bf16-ROUNDED operands -- products of bf16 numbers are exact in fp32, so this holds to fp32
+accumulation error (OP_TOL), i.e. the kernels are exact up to the stated operand rounding (the operator entry points
+take fp32 tensors, round them to bf16 rows first and store fp32, so the comparison stays sharp); (3) whole training
+steps against the float64 oracle (un-rounded) within the mode's own, looser tolerances (BF16_*), stated below and logged
+like the fp32 ones."""
 import ctypes as C
 import os
 
@@ -22,10 +25,6 @@ from _observed import record
 
 pytestmark = pytest.mark.gpu
 
-# the plan keeps launches with fewer than WUN_BF16_MIN_ROWS (default 16384) output rows on the exact-fp32
-# kernels; these tests want every eligible conv of the small configs on the bf16 kernel
-os.environ["WUN_BF16_MIN_ROWS"] = "0"
-
 import wave_u_net_amd as wun                      # noqa: E402
 from wave_u_net_amd import _lib                   # noqa: E402
 from wave_u_net_amd.separator import UnetAudioSeparator   # noqa: E402
@@ -35,10 +34,10 @@ BF16_OUT_TOL = 1e-2      # network outputs vs the float64 oracle, absolute (outp
 BF16_LOSS_TOL = 1e-2     # relative; observed <= 1.6e-3
 BF16_GRAD_TOL = 2.5e-1   # x max|g| per gradient tensor (small nets: few terms average the operand rounding out;
                          # observed <= 1.7e-1 on the 8-filter test nets, <= 6e-2 at full size)
-BF16_INTERP_L2_TOL = 4.5e-1   # bias / interp vectors, relative L2; observed <= 0.15 (3x)
-BF16_INTERP_MAX_TOL = 6e-1    # x max|g| for the learned-interpolation vectors alone: each element is the difference of two long
+BF16_INTERP_L2_TOL = 6e-1     # bias / interp vectors, relative L2; observed <= 0.15 on the small nets, 0.39 on M5 at full size (interp_0, see below)
+BF16_INTERP_MAX_TOL = 7.5e-1    # x max|g| for the learned-interpolation vectors alone: each element is the difference of two long
                               # sums of bf16-rounded products over a handful of positions (interp_0 of M5 at full size: 312
-                              # elements from a 9-position bottleneck row; observed 0.33)
+                              # elements from a 9-position bottleneck row at B = 2; observed 0.33 with fp32 activations in HBM, 0.50 with bf16 ones)
 BF16_GRAD_L2_TOL = 1.1e-1  # per gradient tensor ||g - g_ref||_2 / ||g_ref||_2: the sharper norm for rounding noise (a wrong tap
                          # or a dropped channel group of a narrow layer moves it by O(1/sqrt(taps)) ~ 0.3+); observed <= 3.6e-2 on conv kernels (3x)
 

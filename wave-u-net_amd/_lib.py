@@ -23,7 +23,7 @@ class WunPlanInfo(C.Structure):
 
 
 class WunActivationInfo(C.Structure):
-    _fields_ = [(n, C.c_int64) for n in ("offset", "batch_stride", "pitch", "channels", "frames", "t0", "tstep")]
+    _fields_ = [(n, C.c_int64) for n in ("offset", "batch_stride", "pitch", "channels", "frames", "t0", "tstep", "elem_bytes")]
 
 
 class WunTensorInfo(C.Structure):

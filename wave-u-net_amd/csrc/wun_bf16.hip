@@ -470,13 +470,6 @@ bool conv_bf16_supported(const ConvArgs& a) {
     return true;
 }
 
-// Few output positions: the launch is latency-bound, not matrix-pipe-bound, and the exact-fp32 kernels
-// (batch-folded tiles, split-K) can serve it as well -- a plan may keep such levels on exact arithmetic.
-// min_rows: the plan's threshold on B * Tout (WUN_BF16_MIN_ROWS).
-bool conv_bf16_preferred(const ConvArgs& a, long long min_rows) {
-    return conv_bf16_supported(a) && (long long)a.B * a.Tout >= min_rows;
-}
-
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 static inline int bf16_rows(const ConvArgs& a, int TT) {
@@ -493,8 +486,13 @@ static inline size_t bf16_lds(const ConvArgs& a, int TT, int NT, int nck) {
 static int bf16_pick_nck(const ConvArgs& a, int TT, int NT, int xit) {
     const int planes = a.loader == LOADER_DEINT ? 2 : 1;
     const int maxck = (a.C0 + a.C1 + 31) / 32;
+    // (the HEURISTIC keeps the chunk counts of the round-2..4 kernel, whose single-sample items allowed fewer chunks per
+    //  stage -- 9 / 7 / 4 items of 64-padded rows per thread: they keep the LDS footprint at two workgroups per CU; the
+    //  autotuner may pick any count the pair items hold, conv_bf16_choice_ok)
+    const int xit_old = TT >= 256 ? 9 : (TT >= 128 ? 7 : 4);
     auto fits = [&](int nck) {
-        return bf16_pairs64(planes * bf16_rows(a, TT)) * 4 * nck <= xit * 256 && bf16_lds(a, TT, NT, nck) <= 160 * 1024;
+        return bf16_pairs64(planes * bf16_rows(a, TT)) * 4 * nck <= xit * 256 &&
+               ((planes * bf16_rows(a, TT) + 63) & ~63) * 4 * nck <= xit_old * 256 && bf16_lds(a, TT, NT, nck) <= 160 * 1024;
     };
     // all input channels in one stage -> weights-stationary schedule
     if (maxck <= 3 && fits(maxck)) return maxck;
@@ -657,66 +655,84 @@ hipError_t launch_conv_bf16(const ConvArgs& a_in, hipStream_t s) {
 // even positions (the [:, ::2, :] of :100 in same-padding mode).  ConvArgs: src0 fp32 (xbf = 0), C1 = 0, W fp32 in TF
 // layout [K][Cin][Cout], dst0 / dec bf16 (obf = 1) or fp32; loader DIRECT = stride 1, DEINT = stride 2.
 // ---------------------------------------------------------------------------------------
-template <int SI, int CIN, bool OB>
+// KT: the tap count when it is the shipped 15 (tap loop fully unrolled, no branches), 0 = run-time taps <= 15.  The
+// weights sit in LDS as [cout][tap][cin] (one uniform-address read per tap: a broadcast), staged once per workgroup.
+template <int SI, int CIN, bool OB, int KT>
 __global__ __launch_bounds__(256) void first_conv_kernel(ConvArgs a) {
     using ET = std::conditional_t<OB, bf16_t, float>;
-    constexpr int XW = 3 * SI + WUN_BF_KMAX;                // window for 4 positions, K <= 15
+    __shared__ float wl[48 * WUN_BF_KMAX * 2 + 48];          // N <= 48 output channels per pass (launcher), + their bias
+    constexpr int KM = KT > 0 ? KT : WUN_BF_KMAX;
+    constexpr int XW = 3 * SI + KM;                          // window for 4 positions
+    const int K = KT > 0 ? KT : a.KW;
     const int b = blockIdx.y;
     const int q = ((int)blockIdx.x * 256 + (int)threadIdx.x) * 4;
-    if (q >= a.Tout) return;
-    const int K = a.KW;
-    const int xw = 3 * SI + K;
-    float xv[CIN][XW];
-    const int t0 = q * SI - a.shift;
-#pragma unroll
-    for (int c = 0; c < CIN; ++c) {
-        const float* xr = a.src0 + (long long)b * a.bs0 + (long long)c * a.pitch0 + a.off0;
-#pragma unroll
-        for (int i = 0; i < XW; ++i) {
-            const int t = t0 + i;
-            const int tc = t < 0 ? 0 : (t > a.Tin - 1 ? a.Tin - 1 : t);
-            const float v = xr[tc];
-            xv[c][i] = (i < xw && t >= 0 && t < a.Tin) ? v : 0.f;
-        }
-    }
-    const float* __restrict__ W = a.W;
-    const float* __restrict__ bias = a.bias;
     const bool lrelu = (a.flags & F_LRELU) != 0;
-    const bool full = q + 3 < a.Tout;
     ET* const dst = reinterpret_cast<ET*>(a.dst0) + (long long)b * a.obs0 + a.ooff0;
     ET* const dec = a.dec != nullptr ? reinterpret_cast<ET*>(a.dec) + (long long)b * a.decbs : nullptr;
-    for (int n = 0; n < a.N; ++n) {
-        float acc[4];
-        const float bv = bias != nullptr ? bias[n] : 0.f;
+    float xv[CIN][XW];
+    const int t0 = q * SI - a.shift;
+    if (q < a.Tout) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = bv;
+        for (int c = 0; c < CIN; ++c) {
+            const float* xr = a.src0 + (long long)b * a.bs0 + (long long)c * a.pitch0 + a.off0;
+            if (t0 >= 0 && t0 + XW <= a.Tin) {               // interior: plain loads
 #pragma unroll
-        for (int k = 0; k < WUN_BF_KMAX; ++k) {
-            if (k < K) {
+                for (int i = 0; i < XW; ++i) xv[c][i] = xr[t0 + i];
+            } else {
 #pragma unroll
-                for (int c = 0; c < CIN; ++c) {
-                    const float w = W[((long long)k * CIN + c) * a.N + n];      // uniform: scalar load
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[r] = fmaf(xv[c][r * SI + k], w, acc[r]);
+                for (int i = 0; i < XW; ++i) {
+                    const int t = t0 + i;
+                    const int tc = t < 0 ? 0 : (t > a.Tin - 1 ? a.Tin - 1 : t);
+                    const float v = xr[tc];
+                    xv[c][i] = (t >= 0 && t < a.Tin) ? v : 0.f;
                 }
             }
         }
-        if (lrelu) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = fmaxf(0.2f * acc[r], acc[r]);
+    }
+    for (int nb = 0; nb < a.N; nb += 48) {
+        const int nn = a.N - nb < 48 ? a.N - nb : 48;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nn * K * CIN; i += 256) {
+            const int n = i / (K * CIN), r = i - n * (K * CIN);          // r = tap * CIN + cin
+            wl[n * (KM * CIN) + r] = a.W[(long long)r * a.N + nb + n];
         }
-        const long long row = (long long)n * a.opitch0;
-        if (full) {
-            st4<ET>(dst, row + q, (f32x4){acc[0], acc[1], acc[2], acc[3]});
-        } else {
+        for (int i = threadIdx.x; i < nn; i += 256) wl[48 * KM * CIN + i] = a.bias != nullptr ? a.bias[nb + i] : 0.f;
+        __syncthreads();
+        if (q >= a.Tout) continue;
+        for (int n = 0; n < nn; ++n) {
+            const float* wn = wl + n * (KM * CIN);
+            float acc[4];
+            const float bv = wl[48 * KM * CIN + n];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (q + r < a.Tout) st1<ET>(dst, row + q + r, acc[r]);
-        }
-        if (dec != nullptr) {
-            ET* dr = dec + (long long)n * a.decpitch;
-            st1<ET>(dr, q >> 1, acc[0]);
-            if (q + 2 < a.Tout) st1<ET>(dr, (q >> 1) + 1, acc[2]);
+            for (int r = 0; r < 4; ++r) acc[r] = bv;
+#pragma unroll
+            for (int k = 0; k < KM; ++k) {
+                if (KT > 0 || k < K) {
+#pragma unroll
+                    for (int c = 0; c < CIN; ++c) {
+                        const float w = wn[k * CIN + c];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[r] = fmaf(xv[c][r * SI + k], w, acc[r]);
+                    }
+                }
+            }
+            if (lrelu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = fmaxf(0.2f * acc[r], acc[r]);
+            }
+            const long long row = (long long)(nb + n) * a.opitch0;
+            if (q + 3 < a.Tout) {
+                st4<ET>(dst, row + q, (f32x4){acc[0], acc[1], acc[2], acc[3]});
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (q + r < a.Tout) st1<ET>(dst, row + q + r, acc[r]);
+            }
+            if (dec != nullptr) {
+                ET* dr = dec + (long long)(nb + n) * a.decpitch;
+                st1<ET>(dr, q >> 1, acc[0]);
+                if (q + 2 < a.Tout) st1<ET>(dr, (q >> 1) + 1, acc[2]);
+            }
         }
     }
 }
@@ -737,8 +753,13 @@ hipError_t launch_first_conv(const ConvArgs& a, hipStream_t s) {
     prof_scope_begin("first_conv_kernel", conv_flops(a), s, tag,
                      (double)a.B * a.Tout * ((a.obf ? 2.0 : 4.0) * a.N * (a.dec != nullptr ? 1.5 : 1.0) + 4.0 * a.C0 * (a.loader == LOADER_DEINT ? 2 : 1)));
 #define WUN_FC(SI, CI) \
-    if (a.obf) hipLaunchKernelGGL((first_conv_kernel<SI, CI, true>), grid, dim3(256), 0, s, a); \
-    else hipLaunchKernelGGL((first_conv_kernel<SI, CI, false>), grid, dim3(256), 0, s, a);
+    if (a.KW == 15) { \
+        if (a.obf) hipLaunchKernelGGL((first_conv_kernel<SI, CI, true, 15>), grid, dim3(256), 0, s, a); \
+        else hipLaunchKernelGGL((first_conv_kernel<SI, CI, false, 15>), grid, dim3(256), 0, s, a); \
+    } else { \
+        if (a.obf) hipLaunchKernelGGL((first_conv_kernel<SI, CI, true, 0>), grid, dim3(256), 0, s, a); \
+        else hipLaunchKernelGGL((first_conv_kernel<SI, CI, false, 0>), grid, dim3(256), 0, s, a); \
+    }
     if (a.loader == LOADER_DEINT) { if (a.C0 == 1) { WUN_FC(2, 1) } else { WUN_FC(2, 2) } }
     else { if (a.C0 == 1) { WUN_FC(1, 1) } else { WUN_FC(1, 2) } }
 #undef WUN_FC

@@ -283,7 +283,6 @@ static inline int bf16_image_groups(int C) {
     return best;
 }
 bool conv_bf16_supported(const ConvArgs& a);
-bool conv_bf16_preferred(const ConvArgs& a, long long min_rows);
 hipError_t launch_conv_bf16(const ConvArgs& a, hipStream_t s);
 bool first_conv_supported(const ConvArgs& a);
 hipError_t launch_first_conv(const ConvArgs& a, hipStream_t s);                 // audio-input conv of the bf16 mode

@@ -2131,6 +2131,9 @@ hipError_t launch_wgrad_reduce(const WgradArgs& a, const float* partial, int nsp
 // upsampling (linear / learned), forward and backward
 //   UnetAudioSeparator.py:109-118, InterpolationLayer.py:4-40
 // =====================================================================================
+// (ET: element type of x and y -- float, or bf16_t in the bf16 mode whose activations live in HBM as bf16; the arithmetic
+//  is fp32 either way, ET = float compiles to the plain accesses)
+template <typename ET>
 __global__ void upsample_kernel(UpsampleArgs a) {
     const long long total = (long long)a.B * a.C * a.tup;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -2138,36 +2141,37 @@ __global__ void upsample_kernel(UpsampleArgs a) {
         const int t = (int)(i % a.tup);
         const long long bc = i / a.tup;
         const int c = (int)(bc % a.C), b = (int)(bc / a.C);
-        const float* x = a.x + (long long)b * a.xbs + (long long)c * a.xpitch;
+        const ET* x = reinterpret_cast<const ET*>(a.x) + (long long)b * a.xbs + (long long)c * a.xpitch;
         const int j = t >> 1;
         float v;
         if ((t & 1) == 0) {
-            v = x[j];
+            v = ld1<ET>(x, j);
         } else if (a.w != nullptr) {
             const float s = 1.f / (1.f + __expf(-a.w[c]));
-            const float x1 = (j + 1 < a.n) ? x[j + 1] : 0.f;      // SAME: one zero on the right
-            v = s * x[j] + (1.f - s) * x1;
+            const float x1 = (j + 1 < a.n) ? ld1<ET>(x, j + 1) : 0.f;      // SAME: one zero on the right
+            v = s * ld1<ET>(x, j) + (1.f - s) * x1;
         } else {
-            const float x1 = (j + 1 < a.n) ? x[j + 1] : x[j];     // legacy bilinear clamps
-            v = 0.5f * (x[j] + x1);
+            const float x1 = (j + 1 < a.n) ? ld1<ET>(x, j + 1) : ld1<ET>(x, j);     // legacy bilinear clamps
+            v = 0.5f * (ld1<ET>(x, j) + x1);
         }
-        a.y[(long long)b * a.ybs + (long long)c * a.ypitch + t] = v;
+        st1<ET>(reinterpret_cast<ET*>(a.y), (long long)b * a.ybs + (long long)c * a.ypitch + t, v);
     }
 }
 
 // Vector form (rows 16-byte aligned: the plan's buffers): block = 4 (b, c) rows x 64 lanes, a lane produces 4
 // consecutive outputs from x[2i], x[2i+1], x[2i+2] -- one 8-byte + one 4-byte load, one 16-byte store, no integer
 // division (the scalar kernel spends its time on three 64-bit divisions per element).  Same arithmetic per element.
+template <typename ET>
 __global__ __launch_bounds__(256) void upsample_vec_kernel(UpsampleArgs a) {
     const int row = (int)blockIdx.y * 4 + (int)(threadIdx.x >> 6);
     const int i = (int)blockIdx.x * 64 + (int)(threadIdx.x & 63);          // vector index: outputs 4i .. 4i+3
     if (row >= a.B * a.C || 4 * i >= a.tup) return;
     const int b = row / a.C, c = row - b * a.C;
-    const float* x = a.x + (long long)b * a.xbs + (long long)c * a.xpitch;
-    float* y = a.y + (long long)b * a.ybs + (long long)c * a.ypitch;
+    const ET* x = reinterpret_cast<const ET*>(a.x) + (long long)b * a.xbs + (long long)c * a.xpitch;
+    ET* y = reinterpret_cast<ET*>(a.y) + (long long)b * a.ybs + (long long)c * a.ypitch;
     const int j = 2 * i;
-    const float x0 = x[j];
-    const float x1r = (j + 1 < a.n) ? x[j + 1] : 0.f, x2r = (j + 2 < a.n) ? x[j + 2] : 0.f;
+    const float x0 = ld1<ET>(x, j);
+    const float x1r = (j + 1 < a.n) ? ld1<ET>(x, j + 1) : 0.f, x2r = (j + 2 < a.n) ? ld1<ET>(x, j + 2) : 0.f;
     float o1, o3;
     if (a.w != nullptr) {
         const float sg = 1.f / (1.f + __expf(-a.w[c]));
@@ -2179,31 +2183,35 @@ __global__ __launch_bounds__(256) void upsample_vec_kernel(UpsampleArgs a) {
     }
     const int t = 4 * i;
     if (t + 3 < a.tup) {
-        *reinterpret_cast<f32x4*>(y + t) = (f32x4){x0, o1, x1r, o3};
+        st4<ET>(y, t, (f32x4){x0, o1, x1r, o3});
     } else {
-        y[t] = x0;
-        if (t + 1 < a.tup) y[t + 1] = o1;
-        if (t + 2 < a.tup) y[t + 2] = x1r;
+        st1<ET>(y, t, x0);
+        if (t + 1 < a.tup) st1<ET>(y, t + 1, o1);
+        if (t + 2 < a.tup) st1<ET>(y, t + 2, x1r);
     }
 }
 
 hipError_t launch_upsample(const UpsampleArgs& a, hipStream_t s) {
-    ProfScope ps("upsample_kernel", 0.0, s, "", 4.0 * (double)a.B * a.C * ((double)a.n + a.tup));
+    ProfScope ps("upsample_kernel", 0.0, s, "", (a.bf ? 2.0 : 4.0) * (double)a.B * a.C * ((double)a.n + a.tup));
     if ((a.ypitch & 3) == 0 && (a.ybs & 3) == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0 && (long long)a.B * a.C <= 4 * 65535ll) {
         const int nvec = (a.tup + 3) / 4;
-        hipLaunchKernelGGL(upsample_vec_kernel, dim3((unsigned)((nvec + 63) / 64), (unsigned)((a.B * a.C + 3) / 4)), dim3(256), 0, s, a);
+        const dim3 grid((unsigned)((nvec + 63) / 64), (unsigned)((a.B * a.C + 3) / 4));
+        if (a.bf) hipLaunchKernelGGL(upsample_vec_kernel<bf16_t>, grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(upsample_vec_kernel<float>, grid, dim3(256), 0, s, a);
         return hipGetLastError();
     }
     const long long total = (long long)a.B * a.C * a.tup;
     long long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    if (a.bf) hipLaunchKernelGGL(upsample_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(upsample_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
 __device__ __forceinline__ float sigmoidf_exact(float w) { return 1.f / (1.f + expf(-w)); }
 
 // dz[b][c][i] = lrelu'(x) * ( dy[2i] + wa*dy[2i+1] + wb*dy[2i-1] )
+template <typename ET>
 __global__ void upsample_bwd_kernel(UpsampleBwdArgs a) {
     const long long total = (long long)a.B * a.C * a.n;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -2211,23 +2219,24 @@ __global__ void upsample_bwd_kernel(UpsampleBwdArgs a) {
         const int i = (int)(idx % a.n);
         const long long bc = idx / a.n;
         const int c = (int)(bc % a.C), b = (int)(bc / a.C);
-        const float* dy = a.dy + (long long)b * a.ybs + (long long)c * a.ypitch;
+        const ET* dy = reinterpret_cast<const ET*>(a.dy) + (long long)b * a.ybs + (long long)c * a.ypitch;
         float wa = 0.5f, wb = 0.5f;
         if (a.w != nullptr) { wa = 1.f / (1.f + __expf(-a.w[c])); wb = 1.f - wa; }
-        float g = dy[2 * i];
+        float g = ld1<ET>(dy, 2 * i);
         if (2 * i + 1 < a.tup) {
             float wgt = wa;
             if (a.w == nullptr && i == a.n - 1) wgt = 1.f;       // same-mode legacy clamp: out[2n-1] = x[n-1]
-            g += wgt * dy[2 * i + 1];
+            g += wgt * ld1<ET>(dy, 2 * i + 1);
         }
-        if (i >= 1) g += wb * dy[2 * i - 1];
+        if (i >= 1) g += wb * ld1<ET>(dy, 2 * i - 1);
         const long long xi = (long long)b * a.xbs + (long long)c * a.xpitch + i;
-        g *= (a.x[xi] > 0.f) ? 1.f : 0.2f;
-        a.dz[xi] = g;
+        g *= (ld1<ET>(reinterpret_cast<const ET*>(a.x), xi) > 0.f) ? 1.f : 0.2f;
+        st1<ET>(reinterpret_cast<ET*>(a.dz), xi, g);
     }
 }
 
 // dw[c] = sigmoid'(w[c]) * sum_{b,i} dy[2i+1] * (x[i] - x[i+1])   (x[n] = 0 in same mode)
+template <typename ET>
 __global__ __launch_bounds__(256) void interp_grad_kernel(UpsampleBwdArgs a) {
     __shared__ float red[256];
     const int c = blockIdx.x;
@@ -2235,9 +2244,9 @@ __global__ __launch_bounds__(256) void interp_grad_kernel(UpsampleBwdArgs a) {
     const int nmid = a.tup / 2;               // number of odd outputs
     for (long long idx = threadIdx.x; idx < (long long)a.B * nmid; idx += 256) {
         const int i = (int)(idx % nmid), b = (int)(idx / nmid);
-        const float* x = a.x + (long long)b * a.xbs + (long long)c * a.xpitch;
-        const float x1 = (i + 1 < a.n) ? x[i + 1] : 0.f;
-        s += a.dy[(long long)b * a.ybs + (long long)c * a.ypitch + 2 * i + 1] * (x[i] - x1);
+        const ET* x = reinterpret_cast<const ET*>(a.x) + (long long)b * a.xbs + (long long)c * a.xpitch;
+        const float x1 = (i + 1 < a.n) ? ld1<ET>(x, i + 1) : 0.f;
+        s += ld1<ET>(reinterpret_cast<const ET*>(a.dy), (long long)b * a.ybs + (long long)c * a.ypitch + 2 * i + 1) * (ld1<ET>(x, i) - x1);
     }
     red[threadIdx.x] = s;
     __syncthreads();
@@ -2253,24 +2262,27 @@ __global__ __launch_bounds__(256) void interp_grad_kernel(UpsampleBwdArgs a) {
 
 // Vector form of upsample_bwd_kernel: a lane produces dz[4i .. 4i+3] from dy[8i-1 .. 8i+7] (two 16-byte loads + one
 // scalar) and the mask vector; same arithmetic and summation order per element.
+template <typename ET>
 __global__ __launch_bounds__(256) void upsample_bwd_vec_kernel(UpsampleBwdArgs a) {
     const int row = (int)blockIdx.y * 4 + (int)(threadIdx.x >> 6);
     const int iv = (int)blockIdx.x * 64 + (int)(threadIdx.x & 63);         // vector index: dz[4iv .. 4iv+3]
     if (row >= a.B * a.C || 4 * iv >= a.n) return;
     const int b = row / a.C, c = row - b * a.C;
-    const float* dy = a.dy + (long long)b * a.ybs + (long long)c * a.ypitch;
+    const ET* dy = reinterpret_cast<const ET*>(a.dy) + (long long)b * a.ybs + (long long)c * a.ypitch;
+    const ET* const xall = reinterpret_cast<const ET*>(a.x);
+    ET* const dzall = reinterpret_cast<ET*>(a.dz);
     float wa = 0.5f, wb = 0.5f;
     if (a.w != nullptr) { wa = 1.f / (1.f + __expf(-a.w[c])); wb = 1.f - wa; }
     float d[9];                                                             // d[k] = dy[8iv - 1 + k] (0 outside)
     const int t0 = 8 * iv;
-    d[0] = (t0 >= 1) ? dy[t0 - 1] : 0.f;
+    d[0] = (t0 >= 1) ? ld1<ET>(dy, t0 - 1) : 0.f;
     if (t0 + 7 < a.tup) {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(dy + t0), v1 = *reinterpret_cast<const f32x4*>(dy + t0 + 4);
+        const f32x4 v0 = ld4<ET>(dy, t0), v1 = ld4<ET>(dy, t0 + 4);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { d[1 + k] = v0[k]; d[5 + k] = v1[k]; }
     } else {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) d[1 + k] = (t0 + k < a.tup) ? dy[t0 + k] : 0.f;
+        for (int k = 0; k < 8; ++k) d[1 + k] = (t0 + k < a.tup) ? ld1<ET>(dy, t0 + k) : 0.f;
     }
     const long long xi = (long long)b * a.xbs + (long long)c * a.xpitch + 4 * iv;
     float g[4];
@@ -2287,20 +2299,20 @@ __global__ __launch_bounds__(256) void upsample_bwd_vec_kernel(UpsampleBwdArgs a
         g[k] = v;
     }
     if (4 * iv + 3 < a.n) {
-        const f32x4 xm = *reinterpret_cast<const f32x4*>(a.x + xi);
+        const f32x4 xm = ld4<ET>(xall, xi);
         f32x4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = g[k] * ((xm[k] > 0.f) ? 1.f : 0.2f);
-        *reinterpret_cast<f32x4*>(a.dz + xi) = o;
+        st4<ET>(dzall, xi, o);
     } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (4 * iv + k < a.n) a.dz[xi + k] = g[k] * ((a.x[xi + k] > 0.f) ? 1.f : 0.2f);
+            if (4 * iv + k < a.n) st1<ET>(dzall, xi + k, g[k] * ((ld1<ET>(xall, xi + k) > 0.f) ? 1.f : 0.2f));
     }
 }
 
 hipError_t launch_upsample_bwd(const UpsampleBwdArgs& a, hipStream_t s) {
-    ProfScope ps("upsample_bwd_kernel", 0.0, s, "", 4.0 * (double)a.B * a.C * (2.0 * a.n + a.tup));
+    ProfScope ps("upsample_bwd_kernel", 0.0, s, "", (a.bf ? 2.0 : 4.0) * (double)a.B * a.C * (2.0 * a.n + a.tup));
     const long long total = (long long)a.B * a.C * a.n;
     long long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
@@ -2309,14 +2321,18 @@ hipError_t launch_upsample_bwd(const UpsampleBwdArgs& a, hipStream_t s) {
                        (reinterpret_cast<uintptr_t>(a.dz) & 15) == 0 && (long long)a.B * a.C <= 4 * 65535ll;
     if (vecok) {
         const int nvec = (a.n + 3) / 4;
-        hipLaunchKernelGGL(upsample_bwd_vec_kernel, dim3((unsigned)((nvec + 63) / 64), (unsigned)((a.B * a.C + 3) / 4)), dim3(256), 0, s, a);
+        const dim3 grid((unsigned)((nvec + 63) / 64), (unsigned)((a.B * a.C + 3) / 4));
+        if (a.bf) hipLaunchKernelGGL(upsample_bwd_vec_kernel<bf16_t>, grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(upsample_bwd_vec_kernel<float>, grid, dim3(256), 0, s, a);
     } else {
-        hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        if (a.bf) hipLaunchKernelGGL(upsample_bwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(upsample_bwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, a);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (a.w != nullptr && a.dw != nullptr) {
-        hipLaunchKernelGGL(interp_grad_kernel, dim3((unsigned)a.C), dim3(256), 0, s, a);
+        if (a.bf) hipLaunchKernelGGL(interp_grad_kernel<bf16_t>, dim3((unsigned)a.C), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(interp_grad_kernel<float>, dim3((unsigned)a.C), dim3(256), 0, s, a);
         e = hipGetLastError();
     }
     return e;
@@ -2329,9 +2345,12 @@ hipError_t launch_upsample_bwd(const UpsampleBwdArgs& a, hipStream_t s) {
 
 __device__ __forceinline__ int head_block_floats(const HeadArgs& a) { return a.Ko * (a.C + a.F) * a.C + a.C; }
 
+// (FT: element type of the feature map -- float, or bf16_t in the bf16 mode)
+template <typename FT>
 __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a, long long h0, long long h1,
                                                        long long h2, long long h3) {
     extern __shared__ float hw[];
+    const FT* const featp = reinterpret_cast<const FT*>(a.feat);
     const long long hoff[4] = {h0, h1, h2, h3};
     const int blk = a.Ko * (a.C + a.F) * a.C + a.C;
     for (int s = 0; s < a.Sh; ++s)
@@ -2359,11 +2378,11 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a, long long h0,
                     for (int c = 0; c < 2; ++c)
                         if (s < a.Sh && c < a.C) acc[s * 2 + c] += hw[s * blk + ci * a.C + c] * xv;
             }
-            const float* __restrict__ fr = a.feat + (long long)b * a.fbs + tf;
+            const FT* __restrict__ fr = featp + (long long)b * a.fbs + tf;
             for (int f0 = 0; f0 < a.F; f0 += 8) {
                 float xf[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) xf[j] = f0 + j < a.F ? fr[(long long)(f0 + j) * a.fpitch] : 0.f;
+                for (int j = 0; j < 8; ++j) xf[j] = f0 + j < a.F ? ld1<FT>(fr, (long long)(f0 + j) * a.fpitch) : 0.f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
                     if (f0 + j < a.F) {
@@ -2381,7 +2400,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a, long long h0,
             for (int ci = 0; ci < Cin; ++ci) {
                 const float xv = (ci < a.C)
                     ? a.mix_ncw[(long long)b * a.mbs + (long long)ci * a.mpitch + a.moff_feat + tf]
-                    : a.feat[(long long)b * a.fbs + (long long)(ci - a.C) * a.fpitch + tf];
+                    : ld1<FT>(featp, (long long)b * a.fbs + (long long)(ci - a.C) * a.fpitch + tf);
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -2453,9 +2472,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadArgs a) {
 }
 
 // dzfeat[b][f][u] = lrelu'(feat) * sum_{k,s,c} W[s][k][C+f][c] * dpre[s][b][c][u - k + padl]
+template <typename FT>
 __global__ __launch_bounds__(256) void head_dfeat_kernel(HeadArgs a, long long h0, long long h1,
                                                          long long h2, long long h3) {
     extern __shared__ float hw[];
+    const FT* const featp = reinterpret_cast<const FT*>(a.feat);
+    FT* const dzp = reinterpret_cast<FT*>(a.dzfeat);
     const long long hoff[4] = {h0, h1, h2, h3};
     const int blk = a.Ko * (a.C + a.F) * a.C + a.C;
     for (int s = 0; s < a.Sh; ++s)
@@ -2478,12 +2500,12 @@ __global__ __launch_bounds__(256) void head_dfeat_kernel(HeadArgs a, long long h
                 for (int c = 0; c < 2; ++c)
                     dp[s * 2 + c] = (s < a.Sh && c < a.C && t >= 0 && t < a.Tout)
                         ? a.dpre[(long long)s * a.dps + (long long)b * a.dpbs + (long long)c * a.dppitch + t] : 0.f;
-            const float* __restrict__ fr = a.feat + (long long)b * a.fbs + u;
-            float* __restrict__ dr = a.dzfeat + (long long)b * a.fbs + u;
+            const FT* __restrict__ fr = featp + (long long)b * a.fbs + u;
+            FT* __restrict__ dr = dzp + (long long)b * a.fbs + u;
             for (int f0 = 0; f0 < a.F; f0 += 4) {
                 float xf[4], g[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) xf[j] = f0 + j < a.F ? fr[(long long)(f0 + j) * a.fpitch] : 0.f;
+                for (int j = 0; j < 4; ++j) xf[j] = f0 + j < a.F ? ld1<FT>(fr, (long long)(f0 + j) * a.fpitch) : 0.f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     g[j] = 0.f;
@@ -2497,7 +2519,7 @@ __global__ __launch_bounds__(256) void head_dfeat_kernel(HeadArgs a, long long h
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (f0 + j < a.F) dr[(long long)(f0 + j) * a.fpitch] = g[j] * ((xf[j] > 0.f) ? 1.f : 0.2f);
+                    if (f0 + j < a.F) st1<FT>(dr, (long long)(f0 + j) * a.fpitch, g[j] * ((xf[j] > 0.f) ? 1.f : 0.2f));
             }
             continue;
         }
@@ -2512,8 +2534,8 @@ __global__ __launch_bounds__(256) void head_dfeat_kernel(HeadArgs a, long long h
                              a.dpre[(long long)s * a.dps + (long long)b * a.dpbs + (long long)c * a.dppitch + t];
             }
             const long long fi = (long long)b * a.fbs + (long long)f * a.fpitch + u;
-            g *= (a.feat[fi] > 0.f) ? 1.f : 0.2f;
-            a.dzfeat[fi] = g;
+            g *= (ld1<FT>(featp, fi) > 0.f) ? 1.f : 0.2f;
+            st1<FT>(dzp, fi, g);
         }
     }
 }
@@ -2748,9 +2770,10 @@ hipError_t launch_head_fwd_off(const HeadArgs& a, const long long* hoff, hipStre
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     // feature map + mix window read once, all sources written
-    ProfScope ps("head_fwd_kernel", 0.0, s, "", 4.0 * (double)a.B * ((double)a.Tfeat * (a.F + a.C) + (double)a.Tout * a.S * a.C));
-    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)blocks), dim3(256), head_lds(a), s, a, hoff[0],
-                       hoff[1], hoff[2], hoff[3]);
+    const double fb = a.featbf ? 2.0 : 4.0;
+    ProfScope ps("head_fwd_kernel", 0.0, s, "", (double)a.B * ((double)a.Tfeat * (fb * a.F + 4.0 * a.C) + 4.0 * (double)a.Tout * a.S * a.C));
+    if (a.featbf) hipLaunchKernelGGL(head_fwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), head_lds(a), s, a, hoff[0], hoff[1], hoff[2], hoff[3]);
+    else hipLaunchKernelGGL(head_fwd_kernel<float>, dim3((unsigned)blocks), dim3(256), head_lds(a), s, a, hoff[0], hoff[1], hoff[2], hoff[3]);
     return hipGetLastError();
 }
 
@@ -2769,12 +2792,13 @@ hipError_t launch_head_bwd_off(const HeadArgs& a, const long long* hoff, hipStre
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    ProfScope ps("head_dfeat_kernel", 0.0, s, "", 4.0 * (double)a.B * ((double)a.Tout * a.Sh * a.C + (double)a.Tfeat * a.F));
+    // (d(pre-activation) read, the feature map read for its LeakyReLU mask, d(feature map) written)
+    ProfScope ps("head_dfeat_kernel", 0.0, s, "", (double)a.B * (4.0 * (double)a.Tout * a.Sh * a.C + (a.featbf ? 4.0 : 8.0) * (double)a.Tfeat * a.F));
     const long long total = (long long)a.B * a.Tfeat;
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(head_dfeat_kernel, dim3((unsigned)blocks), dim3(256), head_lds(a), s, a, hoff[0],
-                       hoff[1], hoff[2], hoff[3]);
+    if (a.featbf) hipLaunchKernelGGL(head_dfeat_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), head_lds(a), s, a, hoff[0], hoff[1], hoff[2], hoff[3]);
+    else hipLaunchKernelGGL(head_dfeat_kernel<float>, dim3((unsigned)blocks), dim3(256), head_lds(a), s, a, hoff[0], hoff[1], hoff[2], hoff[3]);
     return hipGetLastError();
 }
 

@@ -25,8 +25,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define WUN_NW_TQ 256            // output positions per unit
 
-template <int KT, int SI>
+// ETM: element types of the bf16 mode (activations and their gradients live in HBM as bf16) -- bit 0: src0, bit 1: src1,
+// bit 2: dz hold bf16_t instead of float (NarrowWgradArgs.et); values are widened as they are staged, the arithmetic is fp32.
+template <int B> struct NwEt { typedef float T; };
+template <> struct NwEt<1> { typedef bf16_t T; };
+
+template <int KT, int SI, int ETM>
 __global__ __launch_bounds__(256) void narrow_wgrad_kernel(NarrowWgradArgs a) {
+    typedef typename NwEt<ETM & 1>::T X0T;
+    typedef typename NwEt<(ETM >> 1) & 1>::T X1T;
+    typedef typename NwEt<(ETM >> 2) & 1>::T ZT;
     extern __shared__ __attribute__((aligned(16))) float nlds[];
     constexpr int TQ = WUN_NW_TQ;
     constexpr int XWIN = 3 * SI + KT;                       // x values one thread needs for 4 positions
@@ -71,8 +79,8 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(NarrowWgradArgs a) {
                 const int t = t0 + x;
                 v[e] = 0.f;
                 if (i < Ctot * XW && t >= 0 && t < a.Tin)
-                    v[e] = c < a.C0 ? a.src0[(long long)b * a.bs0 + (long long)c * a.pitch0 + a.off0 + t]
-                                    : a.src1[(long long)b * a.bs1 + (long long)(c - a.C0) * a.pitch1 + a.off1 + t];
+                    v[e] = c < a.C0 ? ld1<X0T>(reinterpret_cast<const X0T*>(a.src0), (long long)b * a.bs0 + (long long)c * a.pitch0 + a.off0 + t)
+                                    : ld1<X1T>(reinterpret_cast<const X1T*>(a.src1), (long long)b * a.bs1 + (long long)(c - a.C0) * a.pitch1 + a.off1 + t);
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -89,9 +97,9 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(NarrowWgradArgs a) {
                 const int s = r / a.Nper, c = r - s * a.Nper;
                 v[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (i < a.N * (TQ / 4) && q0 + q < a.Tq) {
-                    const float* zp = a.dz + (long long)s * a.zss + (long long)b * a.dzbs + (long long)c * a.dzpitch + q0 + q;
-                    if (q0 + q + 3 < a.dzpitch) v[e] = *reinterpret_cast<const f32x4*>(zp);
-                    else for (int k = 0; k < 4; ++k) if (q0 + q + k < a.Tq) v[e][k] = zp[k];
+                    const ZT* zp = reinterpret_cast<const ZT*>(a.dz) + (long long)s * a.zss + (long long)b * a.dzbs + (long long)c * a.dzpitch + q0 + q;
+                    if (q0 + q + 3 < a.dzpitch) v[e] = ld4<ZT>(zp, 0);
+                    else for (int k = 0; k < 4; ++k) if (q0 + q + k < a.Tq) v[e][k] = ld1<ZT>(zp, k);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) if (q0 + q + k >= a.Tq) v[e][k] = 0.f;
                 }
@@ -154,8 +162,9 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(NarrowWgradArgs a) {
 // row into KT + 1 accumulators per row.  At the end the 64 lanes of a wave are summed per accumulator with a fixed DPP
 // tree (row_shr 1, 2, 4, 8, then the four row totals in order) and the workgroup writes one partial vector -- the layout
 // narrow_wgrad_reduce_kernel expects.
-template <int KT, int SI, int NPW, bool PF>
+template <int KT, int SI, int NPW, bool PF, typename ZT>
 __global__ __launch_bounds__(64 * (24 / NPW)) void narrow_stream_kernel(NarrowWgradArgs a) {
+    const ZT* const dzp = reinterpret_cast<const ZT*>(a.dz);
     constexpr int XWIN = 3 * SI + KT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -184,7 +193,7 @@ __global__ __launch_bounds__(64 * (24 / NPW)) void narrow_stream_kernel(NarrowWg
         const int q = qt * 256 + 4 * lane;                      // first of this lane's four positions
         const int t0 = q * SI - a.shift;                        // input sample under tap 0 of position q
         const float* xr = a.src0 + (long long)b * a.bs0 + a.off0;
-        const float* zb = a.dz + (long long)b * a.dzbs + q;
+        const ZT* zb = dzp + (long long)b * a.dzbs + q;
         // interior unit (wave-uniform): every sample of every lane inside the row, every position below Tq
         const int tq_lo = qt * 256 * SI - a.shift, tq_hi = (qt * 256 + 255) * SI - a.shift + KT - 1;
         const bool interior = tq_lo >= 0 && tq_hi < a.Tin && qt * 256 + 255 < a.Tq && qt * 256 + 255 < a.dzpitch;
@@ -193,7 +202,7 @@ __global__ __launch_bounds__(64 * (24 / NPW)) void narrow_stream_kernel(NarrowWg
 #pragma unroll
             for (int i = 0; i < XWIN; ++i) xv[i] = xp[i];
 #pragma unroll
-            for (int n = 0; n < NPW; ++n) z[n] = *reinterpret_cast<const f32x4*>(zb + zrow[n]);
+            for (int n = 0; n < NPW; ++n) z[n] = ld4<ZT>(zb, zrow[n]);
         } else {
 #pragma unroll
             for (int i = 0; i < XWIN; ++i) {
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(64 * (24 / NPW)) void narrow_stream_kernel(NarrowWg
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int qq = q + r < a.Tq ? q + r : a.Tq - 1;
-                    const float v = a.dz[(long long)b * a.dzbs + zrow[n] + qq];
+                    const float v = ld1<ZT>(dzp, (long long)b * a.dzbs + zrow[n] + qq);
                     z[n][r] = q + r < a.Tq ? v : 0.f;
                 }
             }
@@ -359,9 +368,16 @@ hipError_t launch_narrow_wgrad(NarrowWgradArgs a, hipStream_t s) {
         char tag[160];
         snprintf(tag, sizeof(tag), "C=1 N=%d T=%d K=%d stride=%d B=%d nsplit=%d stream", a.N, a.Tq, a.KW, a.stride, a.B, a.nsplit);
         prof_scope_begin("narrow_wgrad_kernel", 2.0 * a.KW * (double)a.N * (double)a.Tq * a.B, s, tag,
-                         4.0 * (double)a.B * a.Tq * ((double)a.N + (double)a.stride));
-        if (a.stride == 2) hipLaunchKernelGGL((narrow_stream_kernel<15, 2, WUN_NS_NPW, WUN_NS_PF>), dim3((unsigned)a.nsplit), dim3(64 * (24 / WUN_NS_NPW)), 0, s, a);
-        else hipLaunchKernelGGL((narrow_stream_kernel<15, 1, WUN_NS_NPW, WUN_NS_PF>), dim3((unsigned)a.nsplit), dim3(64 * (24 / WUN_NS_NPW)), 0, s, a);
+                         (double)a.B * a.Tq * (((a.et & 4) ? 2.0 : 4.0) * a.N + 4.0 * a.stride));
+        if (a.et & ~4) { prof_scope_end(s); return hipErrorInvalidValue; }      // (the audio itself is always fp32)
+        const dim3 blk(64 * (24 / WUN_NS_NPW));
+        if (a.et & 4) {
+            if (a.stride == 2) hipLaunchKernelGGL((narrow_stream_kernel<15, 2, WUN_NS_NPW, WUN_NS_PF, bf16_t>), dim3((unsigned)a.nsplit), blk, 0, s, a);
+            else hipLaunchKernelGGL((narrow_stream_kernel<15, 1, WUN_NS_NPW, WUN_NS_PF, bf16_t>), dim3((unsigned)a.nsplit), blk, 0, s, a);
+        } else {
+            if (a.stride == 2) hipLaunchKernelGGL((narrow_stream_kernel<15, 2, WUN_NS_NPW, WUN_NS_PF, float>), dim3((unsigned)a.nsplit), blk, 0, s, a);
+            else hipLaunchKernelGGL((narrow_stream_kernel<15, 1, WUN_NS_NPW, WUN_NS_PF, float>), dim3((unsigned)a.nsplit), blk, 0, s, a);
+        }
         prof_scope_end(s);
         return hipGetLastError();
     }
@@ -372,10 +388,14 @@ hipError_t launch_narrow_wgrad(NarrowWgradArgs a, hipStream_t s) {
     snprintf(tag, sizeof(tag), "C=%d N=%d T=%d K=%d stride=%d B=%d nsplit=%d", a.C0 + a.C1, a.N, a.Tq, a.KW, a.stride, a.B, a.nsplit);
     // (bandwidth-bound: dz rows + the input rows they touch streamed once)
     prof_scope_begin("narrow_wgrad_kernel", 2.0 * a.KW * (double)(a.C0 + a.C1) * a.N * (double)a.Tq * a.B, s, tag,
-                     4.0 * (double)a.B * a.Tq * ((double)a.N + (double)(a.C0 + a.C1) * a.stride));
-#define WUN_NWL(K, S) \
-    if (KT == K && a.stride == S) { \
-        auto kern = narrow_wgrad_kernel<K, S>; \
+                     (double)a.B * a.Tq * (((a.et & 4) ? 2.0 : 4.0) * a.N + (((a.et & 1) ? 2.0 : 4.0) * a.C0 + ((a.et & 2) ? 2.0 : 4.0) * a.C1) * a.stride));
+    // element-type combinations the plan produces: all fp32; the bf16 mode's audio-input conv (fp32 audio, bf16 dz);
+    // the bf16 mode's head (fp32 audio + bf16 feature map, fp32 d(pre-activation))
+    if (a.et != 0 && a.et != 4 && a.et != 2) { prof_scope_end(s); return hipErrorInvalidValue; }
+#define WUN_NWL(K, S) WUN_NWE(K, S, 0) WUN_NWE(K, S, 4) WUN_NWE(K, S, 2)
+#define WUN_NWE(K, S, E) \
+    if (KT == K && a.stride == S && a.et == E) { \
+        auto kern = narrow_wgrad_kernel<K, S, E>; \
         static size_t allowed = 64 * 1024; \
         if (lds > allowed) { \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -386,6 +406,7 @@ hipError_t launch_narrow_wgrad(NarrowWgradArgs a, hipStream_t s) {
     }
     WUN_NWL(3, 1) WUN_NWL(3, 2) WUN_NWL(15, 1) WUN_NWL(15, 2)
 #undef WUN_NWL
+#undef WUN_NWE
     prof_scope_end(s);
     return hipGetLastError();
 }

@@ -93,7 +93,9 @@ extern "C" int wun_get_padding(const wun_config* cfg, int64_t desired, int64_t* 
 // ---------------------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------------------
-struct Buf { long long off = -1; int C = 0; int T = 0; int pitch = 0; long long bs = 0; };
+// A workspace tensor [B][C][pitch] of fp32 (eb = 4) or bf16 (eb = 2: the activations and their gradients of the bf16
+// mode) elements; `off` is in FLOATS from the workspace base, pitch and bs are in ELEMENTS; rows are 16-byte aligned.
+struct Buf { long long off = -1; int C = 0; int T = 0; int pitch = 0; long long bs = 0; int eb = 4; };
 struct ConvLayer { long long woff = 0, boff = 0; int KW = 0, Cin = 0, Cout = 0;
                    long long wt_full = -1, wt_ph[2] = {-1, -1}, wt_ph2 = -1; int Jp[2] = {0, 0}; int J0 = 0; };
 struct DownShape { int cin, cout, t_in, t_conv, t_dec, tc, cs; };
@@ -114,6 +116,12 @@ struct wun_plan {
     ConvLayer bott;
     std::vector<long long> interp;
     Buf mix_ncw, bott_out, dz_bott;
+    // bf16 mode, output layer too wide for ONE narrow weight-gradient launch ((C + F) * Sh * C > 256: the deep variant):
+    // its weight gradient runs on the bf16 MFMA kernel, which reads bf16 rows only -- bf16 copies of the audio (made in the
+    // forward pass) and of the head's d(pre-activation) (made after head_bwd_kernel); both are a few rows
+    bool head16 = false;
+    Buf mix16;
+    long long dpre16_off = -1; int dp16_pitch = 0;
     std::vector<Buf> dec, skip, ups, upo, dz_dec, dz_skip, d_ups, dz_upo;
     long long dpre_off = -1; int dp_pitch = 0;
     long long partial_off = -1, partial_floats = 0;
@@ -146,7 +154,6 @@ struct wun_plan {
     // workspace, keyed by where the fp32 weights of a launch live (params arena / transposed copy in ws)
     struct BfImg { long long off; int c8p, npad; };
     bool bf16 = false;
-    long long bf16_min_rows = 0;                             // launches with fewer output rows stay on the exact-fp32 kernels (WUN_BF16_MIN_ROWS)
     std::map<std::pair<int, long long>, BfImg> bf_img;       // (1 = in workspace, float offset) -> image
     std::vector<PackDesc> pack;                              // forward images first, then the dgrad images
     int npack_fwd = 0;
@@ -162,14 +169,32 @@ static long long bump(long long& cur, long long n) {
     return off;
 }
 
-static Buf make_buf(long long& cur, int B, int C, int T, const char* name = nullptr, int idx = 0) {
+static Buf make_buf(long long& cur, int B, int C, int T, const char* name = nullptr, int idx = 0, int eb = 4) {
     Buf b;
-    b.C = C; b.T = T; b.pitch = (T + 3) / 4 * 4;
+    const int per16 = 16 / eb;                                        // elements per 16 bytes
+    b.C = C; b.T = T; b.pitch = (T + per16 - 1) / per16 * per16; b.eb = eb;
     b.bs = (long long)C * b.pitch;
-    b.off = bump(cur, (long long)B * b.bs);
+    b.off = bump(cur, ((long long)B * b.bs * eb + 3) / 4);
     if (name != nullptr && getenv("WUN_DUMP_LAYOUT") != nullptr)      // (tools/ws_diff.py: workspace map for debugging)
-        fprintf(stderr, "[wun-layout] %s %d off=%lld B=%d C=%d T=%d pitch=%d\n", name, idx, b.off, B, C, T, b.pitch);
+        fprintf(stderr, "[wun-layout] %s %d off=%lld B=%d C=%d T=%d pitch=%d eb=%d\n", name, idx, b.off, B, C, T, b.pitch, eb);
     return b;
+}
+
+// Can this plan run the bf16 mode (compute_dtype = 1)?  Every conv from level 1 on must be served by the bf16 MFMA
+// kernels -- the activations then live in HBM as bf16 and nothing but those kernels (and the element-type aware
+// elementwise / head / audio-input kernels) reads them: channel counts in whole groups of 8 (num_initial_filters % 8 == 0;
+// every shipped config: 24, the deep variant 48), no tap-less conv phase (a 1-tap filter with context), rows and tensors
+// inside the kernels' 32-bit offsets.  A plan that does not qualify is the exact-fp32 plan (wun_plan_query reports it).
+static bool bf16_plan_ok(const wun_config* c, int B, const std::vector<DownShape>& dsh, int t_b) {
+    if ((c->num_initial_filters & 7) != 0) return false;
+    if (c->context && (c->filter_size < 2)) return false;
+    if (c->filter_size > 15 || c->merge_filter_size > 15) return false;
+    (void)B; (void)t_b;
+    for (const DownShape& d : dsh) {
+        if ((long long)d.t_in + 64 >= (1 << 23)) return false;                                 // 23-bit row elements
+        if ((long long)d.cout * ((d.t_conv + 15) & ~7) * 2 >= (1ll << 31)) return false;        // 32-bit byte offsets per excerpt
+    }
+    return true;
 }
 
 static void crop_offsets(int from, int to, int& start, int& end) {   // Utils.py:120-121
@@ -283,25 +308,40 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
     // ---- workspace ----
     long long w = 0;
     const int B = p->B;
+    // bf16 mode: every activation and activation-gradient tensor is born bf16 (the audio itself, the head's
+    // d(pre-activation), weights, weight gradients and all scratch stay fp32)
+    p->bf16 = cfg->compute_dtype == 1 && bf16_plan_ok(cfg, B, p->dsh, p->t_b);
+    const int eb = p->bf16 ? 2 : 4;
     p->mix_ncw = make_buf(w, B, C, p->Tin, "mix_ncw");
     p->dec.resize(L); p->skip.resize(L); p->dz_dec.resize(L); p->dz_skip.resize(L);
     for (int i = 0; i < L; ++i) {
-        p->dec[i] = make_buf(w, B, p->dsh[i].cout, p->dsh[i].t_dec, "dec", i);
-        p->skip[i] = make_buf(w, B, p->dsh[i].cout, p->dsh[i].tc, "skip", i);
-        if (!same) p->dz_dec[i] = make_buf(w, B, p->dsh[i].cout, p->dsh[i].t_dec, "dz_dec", i);
-        p->dz_skip[i] = make_buf(w, B, p->dsh[i].cout, p->dsh[i].tc, "dz_skip", i);
+        p->dec[i] = make_buf(w, B, p->dsh[i].cout, p->dsh[i].t_dec, "dec", i, eb);
+        p->skip[i] = make_buf(w, B, p->dsh[i].cout, p->dsh[i].tc, "skip", i, eb);
+        if (!same) p->dz_dec[i] = make_buf(w, B, p->dsh[i].cout, p->dsh[i].t_dec, "dz_dec", i, eb);
+        p->dz_skip[i] = make_buf(w, B, p->dsh[i].cout, p->dsh[i].tc, "dz_skip", i, eb);
     }
-    p->bott_out = make_buf(w, B, p->c_b, p->t_b, "bott_out");
-    p->dz_bott = make_buf(w, B, p->c_b, p->t_b, "dz_bott");
+    p->bott_out = make_buf(w, B, p->c_b, p->t_b, "bott_out", 0, eb);
+    p->dz_bott = make_buf(w, B, p->c_b, p->t_b, "dz_bott", 0, eb);
     p->ups.resize(L); p->upo.resize(L); p->d_ups.resize(L); p->dz_upo.resize(L);
     for (int j = 0; j < L; ++j) {
-        p->ups[j] = make_buf(w, B, p->ush[j].c_cur, p->ush[j].t_up, "ups", j);
-        p->d_ups[j] = make_buf(w, B, p->ush[j].c_cur, p->ush[j].t_up, "d_ups", j);
-        p->upo[j] = make_buf(w, B, p->ush[j].cout, p->ush[j].t_conv, "upo", j);
-        p->dz_upo[j] = make_buf(w, B, p->ush[j].cout, p->ush[j].t_conv, "dz_upo", j);
+        p->ups[j] = make_buf(w, B, p->ush[j].c_cur, p->ush[j].t_up, "ups", j, eb);
+        p->d_ups[j] = make_buf(w, B, p->ush[j].c_cur, p->ush[j].t_up, "d_ups", j, eb);
+        p->upo[j] = make_buf(w, B, p->ush[j].cout, p->ush[j].t_conv, "upo", j, eb);
+        p->dz_upo[j] = make_buf(w, B, p->ush[j].cout, p->ush[j].t_conv, "dz_upo", j, eb);
     }
     p->dp_pitch = (p->Tout + 3) / 4 * 4;
     p->dpre_off = bump(w, (long long)p->Sh * B * C * p->dp_pitch);
+    if (p->bf16 && p->Sh > 0) {
+        NarrowWgradArgs t;
+        memset(&t, 0, sizeof(t));
+        t.C0 = C; t.C1 = F; t.KW = Ko; t.stride = 1; t.N = p->Sh * C; t.Nper = C;
+        if (!narrow_wgrad_supported(t) && (C & 1) == 0) {
+            p->head16 = true;
+            p->mix16 = make_buf(w, B, C, p->Tin, "mix16", 0, 2);
+            p->dp16_pitch = (p->Tout + 7) / 8 * 8;
+            p->dpre16_off = bump(w, ((long long)p->Sh * B * C * p->dp16_pitch + 1) / 2);
+        }
+    }
     p->loss_partial_off = bump(w, 1024);
     p->conv_part_floats = 16ll << 20;                       // split-K scratch (64 MiB)
     p->conv_part_off = bump(w, p->conv_part_floats);
@@ -344,8 +384,6 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
 
     // ---- bf16 mode: packed weight images (every conv with >= 8 input channels; the audio-input conv and the
     // output head stay exact fp32) ----
-    p->bf16 = cfg->compute_dtype == 1;
-    if (const char* e = getenv("WUN_BF16_MIN_ROWS")) p->bf16_min_rows = atoll(e);
     if (p->bf16) {
         auto add_img = [&](int in_ws, long long src_off, int K, int Cc, int Nn, int slack = 0) {
             if (Cc < 8 || K < 1) return;
@@ -490,7 +528,7 @@ extern "C" int wun_plan_activation(const wun_plan* p, int32_t kind, int32_t inde
     else if (kind == 3 && index >= 0 && index < p->L) b = &p->upo[(size_t)index];
     if (b == nullptr) return fail(WUN_ERR_INVALID, "wun_plan_activation: unknown kind / index");
     info->offset = b->off; info->batch_stride = b->bs; info->pitch = b->pitch;
-    info->channels = b->C; info->frames = b->T; info->t0 = t0; info->tstep = tstep;
+    info->channels = b->C; info->frames = b->T; info->t0 = t0; info->tstep = tstep; info->elem_bytes = b->eb;
     return WUN_OK;
 }
 
@@ -551,6 +589,7 @@ static HeadArgs head_args(const wun_plan* p, const float* params, float* ws, flo
     h.dzfeat = ws + p->dz_upo[L - 1].off;
     h.loss_partial = ws + p->loss_partial_off;
     h.gscale = 2.0f / ((float)p->S * (float)p->B * (float)p->Tout * (float)p->C);
+    h.featbf = p->bf16 ? 1 : 0;
     return h;
 }
 
@@ -663,11 +702,20 @@ static void time_candidates(const wun_plan* p, hipStream_t s, int n, const std::
 static hipError_t conv_dispatch(const wun_plan* p, ConvArgs a, float* part, long long cap, hipStream_t s, long long at = -1) {
     std::vector<ConvChoice>& vec = p->in_bwd ? p->conv_bwd : p->conv_fwd;
     const size_t idx = at >= 0 ? (size_t)at : p->ci++;
-    if (p->bf16 && conv_bf16_preferred(a, p->bf16_min_rows)) {
-        // bf16-MFMA speed mode: same launch, operands rounded to bf16, weights from the packed image
+    if (p->bf16) {
+        // bf16 mode: every tensor this launch touches holds bf16 elements; the bf16 MFMA kernel is the ONLY kernel that can
+        // serve it (bf16_plan_ok admitted the plan on that condition) -- weights from the packed image
+        if (a.C0 + a.C1 < 8) {
+            // the audio-input conv: fp32 audio in, bf16 activations out, direct conv on the vector pipe (wun_bf16.hip)
+            a.xbf = 0; a.obf = 1;
+            return launch_first_conv(a, s);
+        }
+        a.xbf = 1; a.obf = 1;
+        if (!conv_bf16_supported(a)) return hipErrorInvalidValue;
         const bool in_ws = a.W >= p->cur_ws && a.W < p->cur_ws + p->ws;
         auto it = p->bf_img.find({in_ws ? 1 : 0, (long long)(a.W - (in_ws ? p->cur_ws : p->cur_params))});
-        if (it != p->bf_img.end()) {
+        if (it == p->bf_img.end()) return hipErrorInvalidValue;
+        {
             a.W = p->cur_ws + it->second.off;
             a.wb_c8p = it->second.c8p; a.wb_npad = it->second.npad;
             // tile (positions x columns x channel chunks per stage) autotuned like the fp32 variants
@@ -778,6 +826,9 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
         side_used = true;
     }
     HIP_TRY(launch_btc_to_ncw(mix_btc, ws + p->mix_ncw.off, p->B, p->Tin, p->C, p->mix_ncw.pitch, s));
+    if (p->head16 && training)
+        HIP_TRY(launch_cast_rows_bf16(ws + p->mix_ncw.off, ws + p->mix16.off, (long long)p->B * p->C, p->Tin, p->mix_ncw.pitch,
+                                      p->mix16.pitch, s));
 
     // Context mode: the skip-window conv of level i is only consumed by up level L-1-i, i.e. the windows of the
     // shallow, FLOP-heavy levels are needed LAST.  The deep levels (few positions per excerpt) form a dependent
@@ -886,7 +937,7 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
             ua.x = ws + cur->off; ua.xbs = cur->bs; ua.xpitch = cur->pitch; ua.n = u.t_cur;
             ua.y = ws + p->ups[j].off; ua.ybs = p->ups[j].bs; ua.ypitch = p->ups[j].pitch; ua.tup = u.t_up;
             ua.w = p->interp[j] >= 0 ? params + p->interp[j] : nullptr;
-            ua.C = u.c_cur; ua.B = p->B; ua.context = p->cfg.context;
+            ua.C = u.c_cur; ua.B = p->B; ua.context = p->cfg.context; ua.bf = p->bf16 ? 1 : 0;
             HIP_TRY(launch_upsample(ua, s));
         }
         if (L - 1 - j < defer_below) HIP_TRY(hipStreamWaitEvent(s, p->skip_ev[(size_t)(L - 1 - j)], 0));
@@ -936,11 +987,10 @@ static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const Conv
     }
     // bf16 speed mode: operands rounded to bf16 in LDS (same tiles, same partial layout); launches with few
     // positions are latency-bound and stay exact fp32
-    if (p->bf16 && wgrad_bf16_supported(parts[0])) {
-        long long rows = 0;
-        for (int i = 0; i < nparts; ++i) rows += (long long)parts[i].B * parts[i].Tq;
-        if (rows >= p->bf16_min_rows)
-            for (int i = 0; i < nparts; ++i) parts[i].bf16 = 1;
+    if (p->bf16) {
+        // bf16 mode: inputs and gradients are bf16 tensors, the bf16 kernel is the only reader
+        if (!wgrad_bf16_supported(parts[0])) return fail(WUN_ERR_UNSUPPORTED, "bf16 mode: weight-gradient shape not served by the bf16 kernel");
+        for (int i = 0; i < nparts; ++i) { parts[i].bf16 = 1; parts[i].sbf = 1; }
     }
     // weight gradients alternate between two side streams; each has its own half of the partial buffer
     const long long pcap = p->partial_floats / 2;
@@ -1291,7 +1341,9 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
     HIP_TRY(launch_loss_finish(h.loss_partial, head_bwd_blocks(h),
                                1.0f / ((float)p->S * (float)p->B * (float)p->Tout * (float)p->C), loss, s));
     bool head_done = false;
-    if (p->Sh > 0) {
+    if (p->head16)
+        HIP_TRY(launch_cast_rows_bf16(h.dpre, ws + p->dpre16_off, (long long)p->Sh * p->B * C, p->Tout, h.dppitch, p->dp16_pitch, s));
+    if (p->Sh > 0 && !p->head16) {
         // every source's output conv in ONE direct-reduction launch (OutputLayer.py:8,15): dz rows = (source, channel)
         NarrowWgradArgs nw;
         memset(&nw, 0, sizeof(nw));
@@ -1300,19 +1352,36 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
         nw.Tin = p->t_feat; nw.shift = h.padl; nw.KW = Ko; nw.stride = 1;
         nw.dz = h.dpre; nw.zss = h.dps; nw.dzbs = h.dpbs; nw.dzpitch = h.dppitch;
         nw.N = p->Sh * C; nw.Nper = C; nw.Tq = p->Tout; nw.B = p->B;
-        if (narrow_wgrad_supported(nw) && getenv("WUN_NO_NARROW") == nullptr) {
+        nw.et = p->bf16 ? 2 : 0;                                  // fp32 audio + (bf16) feature map, fp32 d(pre-activation)
+        if (narrow_wgrad_supported(nw) && (p->bf16 || getenv("WUN_NO_NARROW") == nullptr)) {
             long long woff[4] = {0, 0, 0, 0}, boff[4] = {0, 0, 0, 0};
             for (int sh = 0; sh < p->Sh; ++sh) { woff[sh] = p->head[sh].woff; boff[sh] = p->head[sh].boff; }
             if ((rc = run_narrow_wgrad(p, &nw, 1, woff, boff, ws, grads, s, wstream()))) return rc;
+            head_done = true;
+        } else if (p->bf16) {
+            // bf16 mode: the head's inputs are the fp32 audio and the bf16 feature map -- only the narrow kernels read
+            // that mix.  More (input channel, output row) pairs than one launch holds (the deep variant: 50 x 6): one
+            // launch per source
+            nw.N = nw.Nper = C;
+            if (!narrow_wgrad_supported(nw)) return fail(WUN_ERR_UNSUPPORTED, "bf16 mode: output-layer shape not served by the narrow weight-gradient kernels");
+            for (int sh = 0; sh < p->Sh; ++sh) {
+                NarrowWgradArgs one = nw;
+                one.dz = h.dpre + (long long)sh * h.dps;
+                const long long woff[4] = {p->head[sh].woff, 0, 0, 0}, boff[4] = {p->head[sh].boff, 0, 0, 0};
+                if ((rc = run_narrow_wgrad(p, &one, 1, woff, boff, ws, grads, s, wstream()))) return rc;
+            }
             head_done = true;
         }
     }
     for (int sh = 0; sh < p->Sh && !head_done; ++sh) {
         WgradArgs w = wgrad_base(p);
-        wset_src0(w, ws, p->mix_ncw, p->in_crop_start, C);
+        wset_src0(w, ws, p->head16 ? p->mix16 : p->mix_ncw, p->in_crop_start, C);
         wset_src1(w, ws, p->upo[L - 1], 0, F);
         w.Tin = p->t_feat; w.shift = h.padl; w.KW = Ko;
-        wset_dz(w, h.dpre + (long long)sh * h.dps, h.dpbs, h.dppitch, C, p->Tout);
+        if (p->head16)       // (bf16 rows: element strides; the float* base advances by half as many floats)
+            wset_dz(w, ws + p->dpre16_off + ((long long)sh * p->B * C * p->dp16_pitch) / 2, (long long)C * p->dp16_pitch, p->dp16_pitch, C, p->Tout);
+        else
+            wset_dz(w, h.dpre + (long long)sh * h.dps, h.dpbs, h.dppitch, C, p->Tout);
         if ((rc = run_wgrad(p, &w, 1, p->head[sh], ws, grads, s, wstream()))) return rc;
     }
     if (p->Sh > 0 && (rc = ready2(p->head[0].woff))) return rc;
@@ -1362,7 +1431,7 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
             ub.dz = ws + dzprev.off;
             ub.w = p->interp[j] >= 0 ? params + p->interp[j] : nullptr;
             ub.dw = p->interp[j] >= 0 ? grads + p->interp[j] : nullptr;
-            ub.C = u.c_cur; ub.B = p->B; ub.context = p->cfg.context;
+            ub.C = u.c_cur; ub.B = p->B; ub.context = p->cfg.context; ub.bf = p->bf16 ? 1 : 0;
             HIP_TRY(launch_upsample_bwd(ub, s));
         }
     }
@@ -1401,6 +1470,7 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
             for (int k = 0; k < 2; ++k) {
                 nw[k].src0 = ws + x.off; nw[k].bs0 = x.bs; nw[k].pitch0 = x.pitch; nw[k].C0 = d.cin;
                 nw[k].KW = Kd; nw[k].N = nw[k].Nper = d.cout; nw[k].B = p->B;
+                nw[k].et = p->bf16 ? 4 : 0;                       // fp32 audio, (bf16) dz
             }
             if (same) {
                 nw[0].Tin = d.t_in; nw[0].shift = padD; nw[0].stride = 1; nw[0].off0 = 0;
@@ -1411,7 +1481,10 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
                 nw[1].Tin = d.tc + Kd - 1; nw[1].shift = 0; nw[1].stride = 1; nw[1].off0 = d.cs;
                 nw[1].dz = ws + p->dz_skip[0].off; nw[1].dzbs = p->dz_skip[0].bs; nw[1].dzpitch = p->dz_skip[0].pitch; nw[1].Tq = d.tc;
             }
-            narrow = narrow_wgrad_supported(nw[0]) && (same || narrow_wgrad_supported(nw[1])) && getenv("WUN_NO_NARROW") == nullptr && getenv("WUN_NO_NARROW_DOWN0") == nullptr;
+            narrow = narrow_wgrad_supported(nw[0]) && (same || narrow_wgrad_supported(nw[1])) &&
+                     (p->bf16 || (getenv("WUN_NO_NARROW") == nullptr && getenv("WUN_NO_NARROW_DOWN0") == nullptr));
+            // (bf16 mode: the narrow kernels are the only ones that read fp32 audio against bf16 gradients)
+            if (p->bf16 && !narrow) return fail(WUN_ERR_UNSUPPORTED, "bf16 mode: audio-input conv shape not served by the narrow weight-gradient kernels");
         }
         if (narrow) {
             if ((rc = flush_wgrads())) return rc;
@@ -1464,7 +1537,7 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
                 }
                 // (bf16 mode: always fused when the channel count allows -- one launch, the gradient tile staged once,
                 //  contiguous 32-byte stores instead of two stride-2 scatter passes)
-                if ((d.cin & 3) == 0 && ((p->bf16 && conv_bf16_preferred(f, p->bf16_min_rows)) ||
+                if ((d.cin & 3) == 0 && (p->bf16 ||
                                          (f.Tout >= 256 && conv_natural_wgs_phase2(f) >= 256))) {
                     HIP_TRY(conv_dispatch(p, f, ws + p->conv_part_off, p->conv_part_floats / 2, s));
                 } else {
@@ -1516,13 +1589,14 @@ extern "C" int wun_plan_tune(const wun_plan* p, const float* params, const float
 // order of this library build and the number of entries per section, so a table written for
 // another plan, another library build or truncated on disk is rejected at import.
 #define WUN_TUNE_ORDER "r4a"      /* bump whenever the order / number of conv or wgrad launches changes */
+#define WUN_TUNE_ORDER_BF16 "r5b" /* ... of the bf16 mode (round 5: bf16 activations in HBM, other tile menu limits) */
 static std::string tune_header(const wun_plan* p, size_t ncf, size_t ncb, size_t nwg) {
     char line[320];
     const wun_config& c = p->cfg;
     snprintf(line, sizeof(line),
              "wun-tune 2 order=%s variants=%d B=%d Tin=%lld L=%d F=%d K=%d,%d,%d ups=%d out=%d ctx=%d S=%d C=%d act=%d "
              "dt=%d arena=%lld cf=%zu cb=%zu wg=%zu",
-             WUN_TUNE_ORDER, conv_num_variants(), p->B, (long long)p->Tin, p->L, c.num_initial_filters, c.filter_size,
+             p->bf16 ? WUN_TUNE_ORDER_BF16 : WUN_TUNE_ORDER, conv_num_variants(), p->B, (long long)p->Tin, p->L, c.num_initial_filters, c.filter_size,
              c.merge_filter_size, c.output_filter_size, c.upsampling, c.output_type, c.context, c.num_sources,
              c.num_channels, c.output_activation, c.compute_dtype, (long long)p->arena, ncf, ncb, nwg);
     std::string h = line;
@@ -1627,6 +1701,31 @@ static float* op_scratch() {
         (void)hipGetLastError();
     }
     return buf;
+}
+
+// The bf16 kernels read bf16 rows (the plan's activations are born bf16); the single-operator entry points receive fp32
+// tensors and convert them first -- rounding to nearest even, exactly what "operands rounded to bf16" means -- into a
+// process-wide temporary (slot 0 / 1) that grows on demand.  Rows are re-pitched to 16 bytes.
+static void* op_bf16_tmp(int slot, size_t bytes) {
+    static void* buf[2] = {nullptr, nullptr};
+    static size_t cap[2] = {0, 0};
+    if (bytes > cap[slot]) {
+        (void)hipDeviceSynchronize();
+        if (buf[slot]) (void)hipFree(buf[slot]);
+        buf[slot] = nullptr; cap[slot] = 0;
+        const size_t want = bytes + (bytes >> 2) + 4096;
+        if (hipMalloc(&buf[slot], want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        cap[slot] = want;
+    }
+    return buf[slot];
+}
+static inline int pad8(int t) { return (t + 7) / 8 * 8; }
+// fp32 [rows][spitch] (T valid) -> bf16 [rows][pad8(T)] in temporary `slot`; returns the bf16 base or null
+static const float* op_to_bf16(int slot, const float* src, long long rows, int T, long long spitch, hipStream_t s) {
+    void* dst = op_bf16_tmp(slot, (size_t)rows * pad8(T) * 2 + 64);
+    if (!dst) return nullptr;
+    if (launch_cast_rows_bf16(src, dst, rows, T, spitch, pad8(T), s) != hipSuccess) return nullptr;
+    return reinterpret_cast<const float*>(dst);
 }
 
 static hipError_t op_launch_conv(ConvArgs a, hipStream_t s) {
@@ -1754,6 +1853,15 @@ extern "C" int wun_op_conv1d_wgrad(const float* x, const float* dz, float* dw, f
         w.nsplit = std::min(std::max(1, -g_op_wg_nsplit / wgrad_win_tiles(w)), wgrad_max_units(w));
     part = (float*)(((uintptr_t)part + 255) & ~(uintptr_t)255);
     w.out = part; w.direct = 0; w.split_base = 0;      // always through the split reduction (dw and db are separate buffers)
+    if (w.bf16) {
+        // the bf16 kernel reads bf16 rows: convert the repacked copies of x and dz
+        w.src0 = op_to_bf16(0, xs, (long long)batch * cin, t_in, xp, s);
+        w.dz = op_to_bf16(1, zs, (long long)batch * cout, t_out, zp, s);
+        if (!w.src0 || !w.dz) return fail(WUN_ERR_NOMEM, "bf16 temporary");
+        w.pitch0 = pad8(t_in); w.bs0 = (long long)cin * w.pitch0;
+        w.dzpitch = pad8(t_out); w.dzbs = (long long)cout * w.dzpitch;
+        w.sbf = 1;
+    }
     HIP_TRY(launch_wgrad(w, s));
     HIP_TRY(launch_wgrad_reduce(w, part, w.nsplit, dw, db, s));
     return WUN_OK;
@@ -1869,6 +1977,10 @@ extern "C" int wun_op_conv1d_bf16(const float* x, const float* w, const float* b
     a.Tin = t_in; a.shift = pad_left; a.bias = bias; a.KW = k; a.N = a.N0 = cout; a.Tout = t_out;
     a.flags = lrelu ? F_LRELU : 0;
     a.dst0 = y; a.obs0 = (long long)cout * t_out; a.opitch0 = t_out;
+    // the kernel reads bf16 rows: convert x (fp32 output, obf = 0, keeps the comparison with float64 sharp)
+    a.src0 = op_to_bf16(0, x, (long long)batch * cin, t_in, t_in, s);
+    if (!a.src0) return fail(WUN_ERR_NOMEM, "bf16 temporary");
+    a.pitch0 = pad8(t_in); a.bs0 = (long long)cin * a.pitch0; a.xbf = 1; a.obf = 0;
     if (!conv_bf16_supported(a)) return fail(WUN_ERR_UNSUPPORTED, "shape not served by the bf16 kernel (cin < 8 or k > 15)");
     float* img = (float*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
     PackDesc d;
@@ -1922,6 +2034,9 @@ extern "C" int wun_op_conv1d_dgrad_bf16(const float* dz, const float* w, float* 
         pd.KW = J0; pd.N = 2 * cin; pd.Npad = (2 * cin + 32 + 63) / 64 * 64;
     }
     pd.C8p = bf16_image_groups(cout);
+    a.src0 = op_to_bf16(0, dz, (long long)batch * cout, t_out, t_out, s);
+    if (!a.src0) return fail(WUN_ERR_NOMEM, "bf16 temporary");
+    a.pitch0 = pad8(t_out); a.bs0 = (long long)cout * a.pitch0; a.xbf = 1; a.obf = 0;
     if (!conv_bf16_supported(a)) return fail(WUN_ERR_UNSUPPORTED, "shape not served by the bf16 kernel");
     HIP_TRY(launch_make_wt_one(w, wt, d, s));
     PackDesc* dd = nullptr;

@@ -20,9 +20,10 @@
 // registers; row group 0 only).  Columns: NW tiles of 16 output channels shared by all waves.  The position axis is
 // split over workgroups in units of TK <= 128 positions of one excerpt; every workgroup writes its raw tiles to the
 // tile-major partial buffer and wgrad_bf16_reduce_kernel sums the splits in fixed order (deterministic, no atomics).
-// HBM tensors stay fp32: the operands are rounded to bf16 (nearest even, v_cvt_pk_bf16_f32) when they are written
-// to LDS.  Staging writes are rotated per position group so that the 32-byte rows of 4 neighbouring groups land on
-// different banks.
+// Activations and their gradients live in HBM as bf16 (round 5; WgradArgs.sbf -- the single-operator entry point converts
+// its fp32 arguments first): an item of the input stage is (channel pair, 4 positions) = two 8-byte loads, transposed to
+// four (position, channel pair) dwords with v_perm_b32; a dz item is one 8-byte load written to LDS as it is.  Staging
+// writes are rotated per position group so that the 32-byte rows of 4 neighbouring groups land on different banks.
 #include "wun_internal.h"
 
 #include <cstdio>
@@ -121,8 +122,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a, WgBfK g) {
 #pragma unroll
         for (int n = 0; n < NW; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    f32x4 xra[WUN_WGB_XITP], xrb[WUN_WGB_XITP];       // channels 2*pl and 2*pl + 1 of an item
-    f32x4 zreg[ZIT];
+    u32x2 xra[WUN_WGB_XITP], xrb[WUN_WGB_XITP];       // channels 2*pl and 2*pl + 1 of an item: 4 bf16 positions each
+    u32x2 zreg[ZIT];
     const int TK4 = g.TK >> 2;
     const float inv_tk4 = 1.0f / (float)TK4;
 
@@ -155,8 +156,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a, WgBfK g) {
         const int b = u / a.nQT, qt = u - b * a.nQT;
         const int q0 = qt * g.TK;
         const int tb = (deint ? 2 * q0 : q0) - a.shift;
-        const float* base0 = a.src0 + (long long)b * a.bs0;
-        const float* base1 = (a.C1 > 0) ? a.src1 + (long long)b * a.bs1 : base0;
+        const bf16_t* base0 = reinterpret_cast<const bf16_t*>(a.src0) + (long long)b * a.bs0;
+        const bf16_t* base1 = (a.C1 > 0) ? reinterpret_cast<const bf16_t*>(a.src1) + (long long)b * a.bs1 : base0;
         const int e00 = (tb + a.off0) & ~3, e01 = (tb + a.off1) & ~3;
 #pragma unroll
         for (int i = 0; i < WUN_WGB_XITP; ++i) {
@@ -168,15 +169,15 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a, WgBfK g) {
             c1 = c1 < Ctot ? c1 : Ctot - 1;
             const bool s1 = c >= a.C0;                  // (C0 is even: both channels of a pair come from one source)
             const int pitch = s1 ? a.pitch1 : a.pitch0;
-            const float* base = s1 ? base1 : base0;
+            const bf16_t* base = s1 ? base1 : base0;
             const int cs = s1 ? a.C0 : 0;
             int e = (s1 ? e01 : e00) + ((pk & 0xFFFFF) << 2);
             const int emax = pitch - 4;
             e = e < 0 ? 0 : (e > emax ? emax : e);
-            xra[i] = *reinterpret_cast<const f32x4*>(base + (long long)(c - cs) * pitch + e);
-            xrb[i] = *reinterpret_cast<const f32x4*>(base + (long long)(c1 - cs) * pitch + e);
+            xra[i] = *reinterpret_cast<const u32x2*>(base + (long long)(c - cs) * pitch + e);
+            xrb[i] = *reinterpret_cast<const u32x2*>(base + (long long)(c1 - cs) * pitch + e);
         }
-        const float* zb = a.dz + (long long)b * a.dzbs;
+        const bf16_t* zb = reinterpret_cast<const bf16_t*>(a.dz) + (long long)b * a.dzbs;
         const int qmax = a.dzpitch - 4;
 #pragma unroll
         for (int i = 0; i < ZIT; ++i) {
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a, WgBfK g) {
             const int zro = (pk < 0 && nn < a.N ? nn : 0) * a.dzpitch;
             int q = q0 + (((pk >> 16) & 127) << 2);
             q = q > qmax ? qmax : q;
-            zreg[i] = *reinterpret_cast<const f32x4*>(zb + zro + q);
+            zreg[i] = *reinterpret_cast<const u32x2*>(zb + zro + q);
         }
     };
     // per item: the 4 LDS destinations (element offsets from Xs; unit-invariant) in WRITE order -- write instruction k
@@ -228,22 +229,24 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a, WgBfK g) {
             int pk = xpk[i];
             asm volatile("" : "+v"(pk));
             if (pk < 0) {
-                f32x4 ua = xra[i], ub = xrb[i];
+                const u32x2 ua = xra[i], ub = xrb[i];
+                // d[k] = {channel c, channel c + 1} at position k of the item: low / high halves of the two rows' dwords
+                unsigned d[4];
+                d[0] = __builtin_amdgcn_perm(ub[0], ua[0], 0x05040100u);
+                d[1] = __builtin_amdgcn_perm(ub[0], ua[0], 0x07060302u);
+                d[2] = __builtin_amdgcn_perm(ub[1], ua[1], 0x05040100u);
+                d[3] = __builtin_amdgcn_perm(ub[1], ua[1], 0x07060302u);
                 if (edge) {
                     const int cbl = (pk >> 24) & 15, pl = (pk >> 20) & 15, c4 = pk & 0xFFFFF;
                     const int c = (cb0 + cbl) * 16 + 2 * pl;
                     const int t0 = tb + 4 * c4 - (c >= a.C0 ? delta1 : delta0);    // position in the source's own time axis
-                    const bool va = c < Ctot, vb = c + 1 < Ctot;
+                    const unsigned cm = (c < Ctot ? 0x0000FFFFu : 0u) | (c + 1 < Ctot ? 0xFFFF0000u : 0u);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const bool in = t0 + k >= 0 && t0 + k < a.Tin;
-                        ua[k] = in && va ? ua[k] : 0.f;
-                        ub[k] = in && vb ? ub[k] : 0.f;
+                        d[k] = in ? (d[k] & cm) : 0u;
                     }
                 }
-                unsigned d[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) d[k] = wb_pack2(ua[k], ub[k]);
                 const int rot = norot ? 0 : (pk >> 28) & 3;
                 if (rot & 1) { const unsigned t = d[0]; d[0] = d[1]; d[1] = d[2]; d[2] = d[3]; d[3] = t; }
                 if (rot & 2) { unsigned t = d[0]; d[0] = d[2]; d[2] = t; t = d[1]; d[1] = d[3]; d[3] = t; }
@@ -262,14 +265,15 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a, WgBfK g) {
             int pk = zpk[i];
             asm volatile("" : "+v"(pk));
             if (pk < 0) {
-                f32x4 v = zreg[i];
+                u32x2 v = zreg[i];
                 if (zedge) {
                     const int c4x = ((pk >> 16) & 127) << 2;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (c4x + k >= nq) v[k] = 0.f;
+                    if (c4x >= nq) v[0] &= 0xFFFF0000u;
+                    if (c4x + 1 >= nq) v[0] &= 0x0000FFFFu;
+                    if (c4x + 2 >= nq) v[1] &= 0xFFFF0000u;
+                    if (c4x + 3 >= nq) v[1] &= 0x0000FFFFu;
                 }
-                *reinterpret_cast<u32x2*>(Zs + (pk & 0xFFFF)) = (u32x2){wb_pack2(v[0], v[1]), wb_pack2(v[2], v[3])};
+                *reinterpret_cast<u32x2*>(Zs + (pk & 0xFFFF)) = v;
             }
         }
         (void)b;
@@ -292,9 +296,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a, WgBfK g) {
         for (int i = tid; i < NG * (TKr - g.TK); i += 256) Zs[(i / (TKr - g.TK)) * g.ZPe + g.TK + i % (TKr - g.TK)] = 0;
     if (ab_noload) {
 #pragma unroll
-        for (int i = 0; i < WUN_WGB_XITP; ++i) { xra[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; xrb[i] = xra[i]; }
+        for (int i = 0; i < WUN_WGB_XITP; ++i) { xra[i] = (u32x2){0u, 0u}; xrb[i] = xra[i]; }
 #pragma unroll
-        for (int i = 0; i < ZIT; ++i) zreg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < ZIT; ++i) zreg[i] = (u32x2){0u, 0u};
     }
     if (u0 < u1 && !ab_noload) load_unit(u0);
     for (int u = u0; u < u1; ++u) {
@@ -517,7 +521,7 @@ static hipError_t wgrad_bf16_launch_t(WgradArgs a, const WgradBfGeom& g, hipStre
 }
 
 hipError_t launch_wgrad_bf16(const WgradArgs& a, hipStream_t s) {
-    if (!wgrad_bf16_supported(a)) return hipErrorInvalidValue;
+    if (!wgrad_bf16_supported(a) || !a.sbf) return hipErrorInvalidValue;     // bf16 rows in HBM (the operator entry point converts first)
     if (const char* e = getenv("WUN_WGB_ABL")) const_cast<WgradArgs&>(a).ablate = atoi(e);
     if ((a.pitch0 & 3) || (a.bs0 & 3) || (reinterpret_cast<uintptr_t>(a.src0) & 15) || a.pitch0 < 4) return hipErrorInvalidValue;
     if (a.C1 > 0 && ((a.pitch1 & 3) || (a.bs1 & 3) || (reinterpret_cast<uintptr_t>(a.src1) & 15) || a.pitch1 < 4)) return hipErrorInvalidValue;

@@ -294,7 +294,11 @@ class UnetAudioSeparator(object):
         _lib.check(self._lib.wun_plan_activation(self._active.handle, {"dec": 0, "skip": 1, "bottleneck": 2, "up": 3}[kind],
                                                  int(index), C.byref(info)))
         B = int(self._active.info.batch)
-        flat = self._ws[self._last_key][info.offset:info.offset + B * info.batch_stride]
+        ws = self._ws[self._last_key]
+        if info.elem_bytes == 2:                                   # bf16 mode: activations live in HBM as bfloat16
+            flat = ws[info.offset:].view(torch.bfloat16)[:B * info.batch_stride]
+        else:
+            flat = ws[info.offset:info.offset + B * info.batch_stride]
         view = flat.view(B, int(info.channels), int(info.pitch))[:, :, :int(info.frames)]
         return view, int(info.t0), int(info.tstep)
 
