@@ -272,8 +272,8 @@ def main():
                          "(1-rank group: the collective kernels run and contend for CUs, the data is unchanged)")
     ap.add_argument("--bucket-mib", type=float, default=16.0)
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
-                    help="f32 = the reference's arithmetic (headline); bf16 = the speed mode of BASELINE.json configs[2],[4]: "
-                         "conv / input-gradient MFMA operands in bf16, fp32 accumulate, fp32 HBM tensors / weight gradients / Adam")
+                    help="f32 = the reference's arithmetic (headline); bf16 = the mode of BASELINE.json configs[2],[4]: "
+                         "activations and their gradients live in HBM as bf16, bf16 MFMA, fp32 accumulate / weights / weight gradients / Adam")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
                     help="model_config override (JSON value), e.g. --set num_layers=4 --set num_initial_filters=8")
     ap.add_argument("--dry-run", action="store_true",
@@ -412,7 +412,7 @@ def main():
         "ms_median": float(np.median(step_ms)), "ms_p10": float(np.percentile(step_ms, 10)),
         "ms_p90": float(np.percentile(step_ms, 90)), "ms_max": float(step_ms.max()),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.dtype == "f32" else "bf16 (conv/dgrad MFMA operands; fp32 accumulate, storage, wgrad, Adam)",
+        "dtype": "f32" if args.dtype == "f32" else "bf16 (activations and their gradients in HBM + all MFMA operands; fp32 accumulate, weights, weight gradients, Adam)",
         "data": "synthetic",
         "config": {"workload": ("BASELINE.json configs[1]: M1 (12 levels, 24 ch, 15/5 filters, mono) with context, "
                                 "fwd+bwd+Adam, batch %d/GPU, %d -> %d samples" % (tr.batch, tr.t_in, tr.t_out))
@@ -433,6 +433,57 @@ def main():
                    "achieved_tflops_executed": step_flops / (ms_per_step * 1e9),
                    "step_frac_of_fp32_mfma_peak": step_flops / (ms_per_step * 1e9) / PEAK_FP32_MFMA_TFLOPS},
     }
+
+    # ---- communication diagnostics (N > 1, or --force-allreduce): why the scaling efficiency is what it is ----
+    # Untimed extra steps after the timed region, every rank in lock-step:
+    #   exposed_ms          time the launch stream spends waiting for the gradient all-reduce AFTER its own last backward
+    #                       kernel has finished (HIP events: end of backward -> all buckets reduced), i.e. the communication
+    #                       the overlap did not hide; median over the diagnostic steps, max over ranks
+    #   ms_per_step_no_comm the same step with the all-reduce skipped (same process, same streams and priorities)
+    # ms_per_step - ms_per_step_no_comm = what communication costs in total (exposed wait + contention for CUs / queues).
+    reducer = forced if forced is not None else (tr.reducer if world > 1 else None)
+    if reducer is not None:
+        ndiag = max(3, min(10, args.steps))
+        overlapped = hasattr(reducer, "begin")
+        exposed = []
+        for _ in range(ndiag):
+            tr.sep.get_output(mix, True)
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            if overlapped:
+                tr.sep.loss_and_gradients(targets, *reducer.begin())
+                e0.record()
+                reducer.launch(tr.sep.grads, force=forced is not None)
+                reducer.finish()
+            else:
+                tr.sep.loss_and_gradients(targets)
+                e0.record()
+                reducer.all_reduce(tr.sep.grads)
+            e1.record()
+            tr.sep.adam_step(tr.lr, grad_scale=1.0 if forced is not None else reducer.grad_scale)
+            torch.cuda.synchronize()
+            exposed.append(e0.elapsed_time(e1))
+        barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(ndiag):
+            tr.sep.get_output(mix, True)
+            if overlapped:
+                tr.sep.loss_and_gradients(targets, *reducer.begin())      # bucket events still recorded: same launch sequence
+            else:
+                tr.sep.loss_and_gradients(targets)
+            tr.sep.adam_step(tr.lr, grad_scale=1.0 if forced is not None else reducer.grad_scale)
+        torch.cuda.synchronize()
+        no_comm_ms = 1e3 * (time.perf_counter() - t1) / ndiag
+        stats = torch.tensor([float(np.median(exposed)), no_comm_ms], dtype=torch.float64, device=tr.device)
+        if world > 1:
+            dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+        result["comm"] = {"buckets": len(reducer.buckets), "bytes": 4 * int(sum(e - s for s, e in reducer.buckets)),
+                          "bucket_bytes": [4 * int(e - s) for s, e in reducer.buckets],
+                          "overlapped": bool(overlapped), "exposed_ms": float(stats[0].item()), "diagnostic_steps": ndiag,
+                          "backend": dist.get_backend() if dist.is_initialized() else None}
+        result["ms_per_step_no_comm"] = float(stats[1].item())
+        log("comm: %d buckets, %.1f MB, exposed %.3f ms/step; step without the all-reduce %.3f ms" % (
+            len(reducer.buckets), result["comm"]["bytes"] / 1e6, result["comm"]["exposed_ms"], no_comm_ms))
 
     if not args.no_roofline:
         # a few extra steps with HIP events around every heavy launch (all ranks step together,

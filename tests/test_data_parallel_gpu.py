@@ -97,6 +97,12 @@ def test_bench_launches_itself_two_ranks_on_one_gpu():
     assert d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and d["ms_p10"] <= d["ms_median"] <= d["ms_p90"]
     assert np.isfinite(d["config"]["final_loss"])
+    # the line says WHY the scaling is what it is: communication the overlap did not hide, and the same step without
+    # the all-reduce
+    c = d["comm"]
+    assert c["buckets"] >= 1 and c["bytes"] == sum(c["bucket_bytes"]) and c["bytes"] > 0
+    assert c["exposed_ms"] >= 0.0 and c["overlapped"] is True and c["backend"] == "gloo"
+    assert 0.0 < d["ms_per_step_no_comm"] <= 1.5 * d["ms_per_step"] + 5.0
 
 
 @pytest.mark.gpu
