@@ -422,32 +422,25 @@ __global__ __launch_bounds__(256, (MT == 4 ? 2 : (MT == 2 ? (NW <= 3 ? 3 : 2) : 
     };
 
     int b, q0;
-    // diagnostic switches (WUN_BF_ABL, uniform; only in builds with -DWUN_BF_ABLATION -- the extra branches cost the
-    // narrow layers 4 %): 1 no MFMA, 2 no epilogue, 4 no input staging, 8 no weight DMA
-#ifdef WUN_BF_ABLATION
-    const bool ab_nomfma = a.flags & 0x10000, ab_noepi = a.flags & 0x20000, ab_nox = a.flags & 0x40000, ab_now = a.flags & 0x80000;
-#else
-    constexpr bool ab_nomfma = false, ab_noepi = false, ab_nox = false, ab_now = false;
-#endif
     set_tile(tix0, b, q0);
-    if (!ab_now) dma_w(0, 0);
-    if (!ab_nox) { load_x(0); store_x(0, 0); }
+    dma_w(0, 0);
+    { load_x(0); store_x(0, 0); }
     __syncthreads();
     // ---- one output tile: weights and input window of stage st+1 stream in under the MFMAs of stage st ----
     zero_acc();
     for (int st = 0; st < S; ++st) {
         const bool has_next = st + 1 < S;
         if (has_next) {
-            if (!ab_now) dma_w(st + 1, (st + 1) & 1);
-            if (!ab_nox) load_x(st + 1);
+            dma_w(st + 1, (st + 1) & 1);
+            load_x(st + 1);
         }
-        if (!ab_nomfma) run_stage(st & 1, st & 1);
+        run_stage(st & 1, st & 1);
         if (has_next) {
-            if (!ab_nox) store_x(st + 1, (st + 1) & 1);
+            store_x(st + 1, (st + 1) & 1);
             __syncthreads();
         }
     }
-    if (!ab_noepi) {
+    {
         if (a.obf) epilogue(b, q0, std::true_type{});
         else epilogue(b, q0, std::false_type{});
     }
@@ -599,7 +592,6 @@ hipError_t launch_conv_bf16(const ConvArgs& a_in, hipStream_t s) {
     if (a.msk1 != nullptr) vec = vec && al16(a.msk1);
     if (a.dec != nullptr) vec = vec && (a.decpitch & 1) == 0 && (a.decbs & 1) == 0 && al16(a.dec);
     if (vec) a.flags |= F_VEC4;
-    if (const char* e = getenv("WUN_BF_ABL")) a.flags |= atoi(e) << 16;      // diagnostic: skip phases of the kernel
     // autotuned choice (ConvChoice.variant = kBf16VariantBase + tile code; checked by conv_bf16_choice_ok)
     if (a.force_variant > kBf16VariantBase) {
         const int code = a.force_variant - 1 - kBf16VariantBase;

@@ -162,30 +162,13 @@ std::string prof_end() {
 // (row group, column group) tiles of one split) then hit the same L2 instead of fetching the window
 // once per XCD.
 __device__ __forceinline__ int xcd_contiguous_block(int bid, int grid) {
-#ifdef WUN_NO_XCD_REMAP
-    return bid;
-#else
     const int per = grid >> 3, rem = grid & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     return xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
-#endif
 }
 
 #define WUN_JMAX 15
 
-#ifdef WUN_ABLATION
-// Workgroup life-cycle trace of the conv kernel (diagnostic builds only; WUN_ABLATE bit 64): per workgroup
-// {entry, first chunk staged, chunk loop done, end} shader-clock stamps, HW_ID / XCC_ID and the constant 100 MHz
-// clock at entry / end (effective shader clock = d(stamp) / d(realtime)).
-#define WUN_TRACE_WGS 16384
-__device__ int g_wun_knob[4];      // [0] first-round stagger (cycles per co-resident index), [1] staging priority, [2],[3] trace only launches with (Cin, N)
-__device__ unsigned long long g_wun_trace[WUN_TRACE_WGS * 16];
-#define WUN_TRACE_STAMP(i) do { if (tr_on) trp[i] = __builtin_readcyclecounter(); } while (0)
-#define WUN_TRACE_END() do { if (tr_on) { trp[3] = __builtin_readcyclecounter(); trp[6] = wall_clock64(); } } while (0)
-#else
-#define WUN_TRACE_STAMP(i) do { } while (0)
-#define WUN_TRACE_END() do { } while (0)
-#endif
 
 // floor(n / d) for 0 <= n < 2^22, d >= 1 with inv = 1.0f / d: one multiply + a +/-1 fix-up instead of the ~35
 // instruction integer division (the batch-folded tiles of the deep, launch-latency-bound levels do a dozen of
@@ -255,37 +238,11 @@ __global__ __launch_bounds__(256 * KG) void conv_mfma_kernel(ConvArgs a, int nTT
     const int lane = tid & 63;
     const int li = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifdef WUN_ABLATION
-    const bool tr_on = (a.flags & 16384) && tid == 0 && blockIdx.x < WUN_TRACE_WGS &&
-                       (g_wun_knob[2] == 0 || (g_wun_knob[2] == a.C0 + a.C1 && g_wun_knob[3] == a.N));   // optional launch filter
-    unsigned long long* trp = g_wun_trace + (size_t)(blockIdx.x < WUN_TRACE_WGS ? blockIdx.x : 0) * 16;
-    if (tr_on) {
-        trp[0] = __builtin_readcyclecounter();
-        trp[5] = wall_clock64();
-        trp[4] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
-                 ((unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15) << 32);
-    }
-#endif
-#ifdef WUN_ABLATION
-    {
-        const int lagc = g_wun_knob[0];
-        if (lagc > 0 && blockIdx.x < 1024 && blockIdx.x >= 256) {
-            const long long until = (long long)__builtin_readcyclecounter() + (long long)(blockIdx.x >> 8) * lagc;
-            while ((long long)__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(64);
-        }
-    }
-    const int stprio = g_wun_knob[1];
-#define WUN_PRIO_HI() do { if (stprio) __builtin_amdgcn_s_setprio(2); } while (0)
-#define WUN_PRIO_LO() do { if (stprio) __builtin_amdgcn_s_setprio(0); } while (0)
-    WUN_PRIO_HI();
-#elif !defined(WUN_NO_STAGE_PRIO)   /* raised wave priority for prologue / staging / epilogue code: same-box A/B 8.90 -> 8.87 ms per step */
+    // raised wave priority for prologue / staging / epilogue code (a workgroup that starts beside 3-4 MFMA-bound older waves
+    // otherwise gets only their left-over issue slots): same-box A/B 8.90 -> 8.87 ms per step
 #define WUN_PRIO_HI() __builtin_amdgcn_s_setprio(2)
 #define WUN_PRIO_LO() __builtin_amdgcn_s_setprio(0)
     WUN_PRIO_HI();
-#else
-#define WUN_PRIO_HI() do { } while (0)
-#define WUN_PRIO_LO() do { } while (0)
-#endif
     int bid = xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x);
     const int nt = bid % nNT; bid /= nNT;
     const int tt = bid % nTT; bid /= nTT;
@@ -315,17 +272,8 @@ __global__ __launch_bounds__(256 * KG) void conv_mfma_kernel(ConvArgs a, int nTT
     int ch_hi = ch_lo + a.cps;
     if (ch_hi > nchunks) ch_hi = nchunks;
 
-#ifdef WUN_ABLATION
-    const bool ab_hot = (a.flags & 32768) != 0;
-    const int b_ld = ab_hot ? 0 : b, q0_ld = ab_hot ? 0 : q0;
-    const bool ab_hotst = (a.flags & 65536) != 0;
-    const int b_st = ab_hotst ? 0 : b, q0_st = ab_hotst ? 0 : q0;
-#else
-    const int b_ld = b, q0_ld = q0;
-    const int b_st = b, q0_st = q0;
-#endif
-    const float* src0b = a.src0 + (long long)b_ld * a.bs0 + a.off0;
-    const float* src1b = (a.src1 != nullptr) ? a.src1 + (long long)b_ld * a.bs1 + a.off1 : src0b;
+    const float* src0b = a.src0 + (long long)b * a.bs0 + a.off0;
+    const float* src1b = (a.src1 != nullptr) ? a.src1 + (long long)b * a.bs1 + a.off1 : src0b;
 
     f32x4 acc[MT][NW];
 #pragma unroll
@@ -351,11 +299,11 @@ __global__ __launch_bounds__(256 * KG) void conv_mfma_kernel(ConvArgs a, int nTT
     int xdo[XDIT], wdo[WDIT];                                            // xdo: row << 20 | 4 * granule, or -1 (lane fetches nothing)
     int nvr = 1, e00 = 0, e01 = 0;
     bool xedge = false;
-    const float* vb0 = a.src0 + (long long)b_ld * a.bs0;                 // row bases WITHOUT the crop offset (aligned)
-    const float* vb1 = (a.src1 != nullptr) ? a.src1 + (long long)b_ld * a.bs1 : vb0;
+    const float* vb0 = a.src0 + (long long)b * a.bs0;                 // row bases WITHOUT the crop offset (aligned)
+    const float* vb1 = (a.src1 != nullptr) ? a.src1 + (long long)b * a.bs1 : vb0;
     const int XG = XP >> 2, WG4 = WP >> 2;                               // granules per LDS row
     if constexpr (XVEC) {
-        const int tbase = q0_ld - a.shift;
+        const int tbase = q0 - a.shift;
         nvr = (UW + (dl0 > dl1 ? dl0 : dl1) + 3) >> 2;
         e00 = a.off0 + tbase - dl0;
         e01 = a.off1 + tbase - dl1;
@@ -393,7 +341,7 @@ __global__ __launch_bounds__(256 * KG) void conv_mfma_kernel(ConvArgs a, int nTT
         const int lr = deint ? tid % TPC : tid % TPR;
         const int stride_i = deint ? TPC : TPR;
         const int lim = deint ? 2 * UW : UW;
-        const int tbase = (deint ? 2 * q0_ld : q0_ld) - a.shift;
+        const int tbase = (deint ? 2 * q0 : q0) - a.shift;
         const int seglen = deint ? 2 * fold_seg : fold_seg;
         const float inv_seglen = 1.0f / (float)seglen;
 #pragma unroll
@@ -516,12 +464,6 @@ __global__ __launch_bounds__(256 * KG) void conv_mfma_kernel(ConvArgs a, int nTT
         }
     };
 
-#ifdef WUN_ABLATION
-    const bool ab_noload = a.flags & 256, ab_nostore = a.flags & 512, ab_nomfma = a.flags & 1024,
-               ab_noepi = a.flags & 2048, ab_nobar = a.flags & 4096, ab_nolds = a.flags & 8192;
-#else
-    constexpr bool ab_noload = false, ab_nostore = false, ab_nomfma = false, ab_noepi = false, ab_nobar = false, ab_nolds = false;
-#endif
     // MFMA loop over the taps [j_begin, j_end) of the chunk in LDS buffer `bufoff`.  A k-step is
     // 4 LDS rows (4 input channels) of one tap: KS = CK/4 k-steps per tap.  Operands of the
     // next k-step are read from LDS right after the first MFMA of the current one
@@ -552,13 +494,6 @@ __global__ __launch_bounds__(256 * KG) void conv_mfma_kernel(ConvArgs a, int nTT
         const int wstep = CK * WP;
         float a0[MT], b0[NW], a1[MT], b1[NW];
         auto ldop = [&](const float* x, const float* w, float (&av)[MT], float (&bv)[NW]) {
-            if (ab_nolds) {
-#pragma unroll
-                for (int m = 0; m < MT; ++m) asm volatile("v_mov_b32 %0, %1" : "=v"(av[m]) : "v"(lane));
-#pragma unroll
-                for (int n = 0; n < NW; ++n) asm volatile("v_mov_b32 %0, %1" : "=v"(bv[n]) : "v"(lane));
-                return;
-            }
 #pragma unroll
             for (int m = 0; m < MT; ++m) av[m] = FOLD ? x[arow[m]] : x[m * 16];
 #pragma unroll
@@ -576,9 +511,6 @@ __global__ __launch_bounds__(256 * KG) void conv_mfma_kernel(ConvArgs a, int nTT
         };
         // pin the per-k-step interleave: 1 MFMA, the LDS reads of the next operands, the rest
         auto pin = [&]() {
-#ifdef WUN_NOPIN
-            return;
-#endif
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // MFMA
             __builtin_amdgcn_sched_group_barrier(0x100, MT + NW, 0);        // DS reads (<= MT+NW instrs)
             __builtin_amdgcn_sched_group_barrier(0x008, MT * NW - 1, 0);    // MFMA
@@ -683,53 +615,42 @@ __global__ __launch_bounds__(256 * KG) void conv_mfma_kernel(ConvArgs a, int nTT
     };
 
     if constexpr (XVEC) {
-        WUN_TRACE_STAMP(7);
-        if (ch_lo < ch_hi && !ab_noload) dma_chunk(ch_lo, 0);
-        WUN_TRACE_STAMP(8);
-        WUN_TRACE_STAMP(9);
+        if (ch_lo < ch_hi) dma_chunk(ch_lo, 0);
         for (int chunk = ch_lo; chunk < ch_hi; ++chunk) {
             const int cur = ((chunk - ch_lo) & 1) * LB;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's granules of `chunk` have landed
             __syncthreads();                                            // ... everybody's have; buffer LB - cur is free
-            if (chunk == ch_lo) { WUN_TRACE_STAMP(1); WUN_PRIO_LO(); }
+            if (chunk == ch_lo) WUN_PRIO_LO();
             if (xedge) {
                 zero_fix(chunk, cur);
                 __syncthreads();
             }
-            if (chunk + 1 < ch_hi && !ab_noload) dma_chunk(chunk + 1, LB - cur);
-            if (!ab_nomfma) run_taps(cur, 0, J, (chunk * CKC < a.C0) ? dl0 : dl1);
+            if (chunk + 1 < ch_hi) dma_chunk(chunk + 1, LB - cur);
+            run_taps(cur, 0, J, (chunk * CKC < a.C0) ? dl0 : dl1);
         }
     } else {
     // Pipeline: global loads of chunk c+1 are issued before the MFMAs of chunk c; their LDS
     // writes (to the other buffer) sit in the middle of chunk c's MFMA loop, so they issue in
     // the shadow of the matrix pipe; one barrier per chunk.
-    WUN_TRACE_STAMP(7);
-    if (ch_lo < ch_hi && !ab_noload) load_chunk(ch_lo);
-    WUN_TRACE_STAMP(8);
-    if (ch_lo < ch_hi && !ab_nostore) store_chunk(0, ch_lo);
-    WUN_TRACE_STAMP(9);
+    if (ch_lo < ch_hi) load_chunk(ch_lo);
+    if (ch_lo < ch_hi) store_chunk(0, ch_lo);
     __syncthreads();
-    WUN_TRACE_STAMP(1);
     WUN_PRIO_LO();
-#ifndef WUN_STORE_AT
-#define WUN_STORE_AT 2   /* numerator of the tap-loop fraction (over 4) after which the next chunk is written to LDS */
-#endif
-    const int half = (J * WUN_STORE_AT) / 4;
+    const int half = (J * 2) / 4;    // the next chunk is written to LDS half-way through the tap loop
     for (int chunk = ch_lo; chunk < ch_hi; ++chunk) {
         const int cur = ((chunk - ch_lo) & 1) * LB;
         const bool has_next = chunk + 1 < ch_hi;
         WUN_PRIO_HI();
-        if (has_next && !ab_noload) load_chunk(chunk + 1);
+        if (has_next) load_chunk(chunk + 1);
         WUN_PRIO_LO();
-        if (!ab_nomfma) run_taps(cur, 0, half, 0);
+        run_taps(cur, 0, half, 0);
         WUN_PRIO_HI();
-        if (has_next && !ab_nostore) store_chunk(LB - cur, chunk + 1);
+        if (has_next) store_chunk(LB - cur, chunk + 1);
         WUN_PRIO_LO();
-        if (!ab_nomfma) run_taps(cur, half, J, 0);
-        if (!ab_nobar) __syncthreads();
+        run_taps(cur, half, J, 0);
+        __syncthreads();
     }
     }
-    WUN_TRACE_STAMP(2);
     WUN_PRIO_HI();
 
     if constexpr (KG > 1) {
@@ -745,7 +666,7 @@ __global__ __launch_bounds__(256 * KG) void conv_mfma_kernel(ConvArgs a, int nTT
                     *reinterpret_cast<f32x4*>(&red[((((kg - 1) * MT + m) * NW + n) * 256 + tid) * 4]) = acc[m][n];
         }
         __syncthreads();
-        if (kg > 0) { WUN_TRACE_END(); return; }
+        if (kg > 0) return;
 #pragma unroll
         for (int g = 1; g < KG; ++g)
 #pragma unroll
@@ -778,7 +699,6 @@ __global__ __launch_bounds__(256 * KG) void conv_mfma_kernel(ConvArgs a, int nTT
                 }
             }
         }
-        WUN_TRACE_END();
         return;
     }
 
@@ -791,8 +711,8 @@ __global__ __launch_bounds__(256 * KG) void conv_mfma_kernel(ConvArgs a, int nTT
             const bool accum2 = (a.flags & F_ACCUM) != 0;
             // 8 consecutive outputs t = 2q .. 2q+7 of channel `ncol` (v[2r] = phase 0, v[2r+1] = phase 1 of position q + r)
             auto store8 = [&](int ncol, int m, float (&v)[8]) {
-                const long long rowbase = (long long)b_st * a.obs0 + (long long)ncol * a.opitch0 + a.ooff0;
-                const int q = q0_st + wt0 + m * 16 + lg * 4;
+                const long long rowbase = (long long)b * a.obs0 + (long long)ncol * a.opitch0 + a.ooff0;
+                const int q = q0 + wt0 + m * 16 + lg * 4;
                 const int t0 = 2 * q;
                 if (vec2 && t0 + 7 < a.Tlim) {
                     const long long idx = rowbase + t0;
@@ -877,7 +797,6 @@ __global__ __launch_bounds__(256 * KG) void conv_mfma_kernel(ConvArgs a, int nTT
                 }
             }
         }
-        WUN_TRACE_END();
         return;
     }
 
@@ -885,7 +804,6 @@ __global__ __launch_bounds__(256 * KG) void conv_mfma_kernel(ConvArgs a, int nTT
     const bool lrelu = (a.flags & F_LRELU) != 0;
     const bool accum = (a.flags & F_ACCUM) != 0;
     const bool vec = (a.flags & F_VEC4) != 0;
-    if (ab_noepi && acc[0][0][0] != 12345.678f) return;
 #pragma unroll
     for (int n = 0; n < NW; ++n) {
         const int ncol = n0 + wn0 + n * 16 + li;
@@ -893,17 +811,17 @@ __global__ __launch_bounds__(256 * KG) void conv_mfma_kernel(ConvArgs a, int nTT
         const float bvv = (a.bias != nullptr) ? a.bias[ncol] : 0.f;
         float* dst; const float* msk; long long rowbase;
         if (ncol < a.N0) {
-            rowbase = (long long)b_st * a.obs0 + (long long)ncol * a.opitch0 + a.ooff0;
+            rowbase = (long long)b * a.obs0 + (long long)ncol * a.opitch0 + a.ooff0;
             dst = a.dst0; msk = a.msk0;
         } else {
-            rowbase = (long long)b_st * a.obs1 + (long long)(ncol - a.N0) * a.opitch1 + a.ooff1;
+            rowbase = (long long)b * a.obs1 + (long long)(ncol - a.N0) * a.opitch1 + a.ooff1;
             dst = a.dst1; msk = a.msk1;
         }
         float* decrow = (a.dec != nullptr && ncol < a.N0)
                             ? a.dec + (long long)b * a.decbs + (long long)ncol * a.decpitch : nullptr;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const int q = q0_st + wt0 + m * 16 + lg * 4;
+            const int q = q0 + wt0 + m * 16 + lg * 4;
             if constexpr (FOLD) {
                 int g = fast_div(q, a.Tout, inv_tout), qq = q - g * a.Tout;
                 const bool first = ncol < a.N0;
@@ -965,7 +883,6 @@ __global__ __launch_bounds__(256 * KG) void conv_mfma_kernel(ConvArgs a, int nTT
             }
         }
     }
-    WUN_TRACE_END();
 }
 
 // sums the split-K partial tiles in a fixed order and applies the conv epilogue.  One thread = 4
@@ -1335,18 +1252,7 @@ static hipError_t conv_launch_t(ConvArgs a, int variant, float* part, long long 
         if (e != hipSuccess) return e;
         lds_allowed = lds;
     }
-#ifdef WUN_ABLATION
-    size_t lds_launch = lds;
-    if (const char* e = getenv("WUN_LDS_PAD")) {
-        lds_launch += (size_t)atoi(e) * 1024;
-        if (lds_launch > lds_allowed) {
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_launch);
-            lds_allowed = lds_launch;
-        }
-    }
-#else
     const size_t lds_launch = lds;
-#endif
     int ksplit, cps;
     conv_splitk(a, variant, (part != nullptr && !phase2) ? part_cap : 0, ksplit, cps);
     if (a.force_ksplit > 0 && !phase2) {                         // autotuned choice
@@ -1507,10 +1413,6 @@ hipError_t launch_conv(const ConvArgs& a_in, float* part, long long part_cap, hi
     if (a.dec != nullptr) vec = vec && (a.decpitch & 1) == 0 && (a.decbs & 1) == 0;
     if ((a.flags & F_PHASE2) && !(a.ostride == 1 && a.dst1 == nullptr && vecw)) return hipErrorInvalidValue;
     if (vec) a.flags |= F_VEC4;
-#ifdef WUN_ABLATION
-    if (const char* e = getenv("WUN_ABLATE")) a.flags |= atoi(e) << 8;
-    if (const char* e = getenv("WUN_NOVEC")) if (atoi(e)) a.flags &= ~F_VEC4;
-#endif
     int v = (a.flags & F_PHASE2) ? conv_pick_variant_phase2(a) : conv_pick_variant(a);
     if (a.force_variant > 0 && vecw) {
         v = a.force_variant - 1;
@@ -1534,9 +1436,6 @@ hipError_t launch_conv(const ConvArgs& a_in, float* part, long long part_cap, hi
 #undef WUN_K3F
     }
     if (v >= WUN_FIRST_RETIRED_VARIANT) return hipErrorInvalidValue;
-#ifdef WUN_ABLATION
-    if (const char* e = getenv("WUN_VARIANT")) v = atoi(e);
-#endif
     if (!vecw) {
         // channel counts that are not multiples of 4 (non-shipped configs): scalar weight loads,
         // restricted tile menu
@@ -1609,16 +1508,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a, int nMG
     const int lane = tid & 63;
     const int li = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifdef WUN_ABLATION
-    const bool tr_on = (a.ablate & 64) && tid == 0 && blockIdx.x < WUN_TRACE_WGS;      // workgroup trace (diagnostic builds)
-    unsigned long long* trp = g_wun_trace + (size_t)(blockIdx.x < WUN_TRACE_WGS ? blockIdx.x : 0) * 16;
-    if (tr_on) {
-        trp[0] = __builtin_readcyclecounter();
-        trp[5] = wall_clock64();
-        trp[4] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
-                 ((unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15) << 32);
-    }
-#endif
     int bid = xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x);
     const int ng = bid % nNG; bid /= nNG;
     const int mg = bid % nMG;
@@ -1783,14 +1672,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a, int nMG
     const int u0 = split * a.units_per_split;
     int u1 = u0 + a.units_per_split;
     if (u1 > nunits) u1 = nunits;
-#ifdef WUN_ABLATION
-    const bool wb_noload = a.ablate & 1, wb_nostore = a.ablate & 2, wb_nomfma = a.ablate & 4, wb_noepi = a.ablate & 8;
-#else
     constexpr bool wb_noload = false, wb_nostore = false, wb_nomfma = false, wb_noepi = false;
-#endif
-    WUN_TRACE_STAMP(7);
     if (u0 < u1 && !wb_noload) load_unit(u0);
-    WUN_TRACE_STAMP(1);
     for (int u = u0; u < u1; ++u) {
         const int qt = u % a.nQT;
         int nq = a.Tq - qt * TK; if (nq > TK) nq = TK;
@@ -1855,7 +1738,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a, int nMG
         }
     }
 
-    WUN_TRACE_STAMP(2);
     if (wb_noepi && acc[0][0][0] != 12345.678f) return;
     if (!a.direct) {
         // split partial, tile-major: each wave stores its accumulator tiles as contiguous 1 KiB
@@ -1869,7 +1751,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a, int nMG
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
             for (int n = 0; n < NW; ++n) tile[(mt * NW + n) * 64] = acc[mt][n];
-        WUN_TRACE_END();
         return;
     }
     // single split: final layout directly (weights [K][Cin][Cout], then the bias row)
@@ -2074,9 +1955,6 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
     if ((a.dzpitch & 3) || (a.dzbs & 3) || (reinterpret_cast<uintptr_t>(a.dz) & 15) || a.dzpitch < 4) return hipErrorInvalidValue;
     const WgradGeom g = wgrad_geom(a);
     if ((long long)g.nChMax * g.XW4 > (long long)WUN_WG_XIT * 256) return hipErrorInvalidValue;
-#ifdef WUN_ABLATION
-    if (const char* e = getenv("WUN_ABLATE")) const_cast<WgradArgs&>(a).ablate = atoi(e);
-#endif
 #define WUN_WG(M, N) if (g.MTW == M && g.NW == N) return wgrad_launch_t<M, N>(a, g, s);
     WUN_WG(1, 1) WUN_WG(1, 2) WUN_WG(1, 3)
     WUN_WG(2, 1) WUN_WG(2, 2) WUN_WG(2, 3)
@@ -2849,23 +2727,3 @@ hipError_t launch_head_bwd_off(const HeadArgs& a, const long long* hoff, hipStre
 
 }  // namespace wun
 
-#ifdef WUN_ABLATION
-// diagnostic builds only: copy / clear the conv kernel's workgroup trace (WUN_ABLATE bit 64)
-extern "C" int wun_dbg_set_knob(int idx, int value) {
-    if (idx < 0 || idx >= 4) return -1;
-    return hipMemcpyToSymbol(HIP_SYMBOL(wun::g_wun_knob), &value, sizeof(int), idx * sizeof(int)) == hipSuccess ? 0 : -2;
-}
-extern "C" int wun_dbg_trace_read(unsigned long long* host, int nwg, int clear) {
-    if (nwg > WUN_TRACE_WGS) nwg = WUN_TRACE_WGS;
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (host != nullptr &&
-        hipMemcpyFromSymbol(host, HIP_SYMBOL(wun::g_wun_trace), (size_t)nwg * 16 * sizeof(unsigned long long)) != hipSuccess)
-        return -2;
-    if (clear) {
-        void* p = nullptr;
-        if (hipGetSymbolAddress(&p, HIP_SYMBOL(wun::g_wun_trace)) != hipSuccess) return -3;
-        if (hipMemset(p, 0, sizeof(unsigned long long) * WUN_TRACE_WGS * 16) != hipSuccess) return -4;
-    }
-    return nwg;
-}
-#endif

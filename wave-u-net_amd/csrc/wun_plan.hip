@@ -626,7 +626,7 @@ static int side_init(const wun_plan* p) {
     int prio = p->cfg.exclusive_streams ? least : 0;
     if (const char* e = getenv("WUN_SIDE_PRIO")) prio = (e[0] == 'l') ? least : (e[0] == 'h') ? greatest : 0;
     HIP_TRY(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, prio));
-    if (getenv("WUN_TWO_STREAMS") == nullptr) HIP_TRY(hipStreamCreateWithPriority(&p->side2, hipStreamNonBlocking, prio));
+    HIP_TRY(hipStreamCreateWithPriority(&p->side2, hipStreamNonBlocking, prio));
     p->events.resize(160);
     for (auto& e : p->events) HIP_TRY(hipEventCreateWithFlags(&e, event_flags()));
     return WUN_OK;
@@ -837,13 +837,13 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
     // competing with their own level's decimating conv.
     int defer_below = 0;                                            // levels [0, defer_below) are deferred
     hipStream_t s3 = (p->side2 && s2 != s) ? p->side2 : s2;
-    if (!same && s3 != s2 && getenv("WUN_NO_DEFER") == nullptr) {
+    if (!same && s3 != s2) {
         while (defer_below < L && (long long)p->B * p->dsh[defer_below].t_dec >= 16384) ++defer_below;
         if (L - defer_below < 3) defer_below = 0;                   // no deep chain to hide them under
         // ... and then the deep levels' (small) window convs are deferred as well: ONE event on the caller's stream
         // starts all of them instead of one event per level (each event holds the dependent chain for ~6 us); same-box
         // A/B 9.085 -> 9.04 ms.  (Awaiting the deep ones in groups instead of per level stalls the up path: 9.10-9.16.)
-        if (defer_below > 0 && getenv("WUN_DEFER_SHALLOW_ONLY") == nullptr) defer_below = L;
+        if (defer_below > 0) defer_below = L;
         if (defer_below > 0 && p->skip_ev.size() < (size_t)L) {
             p->skip_ev.resize(L, nullptr);
             for (auto& e : p->skip_ev)
@@ -1237,12 +1237,10 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
         }
         return sig.ready(floor, s2);
     };
-    // Every event recorded on the caller's stream is a barrier packet that holds the dependent chain for ~7 us
-    // (rocprofv3 timeline), a third of a deep level's kernel.  The weight gradients of the levels with few positions
-    // CAN therefore be queued in batches (one event for up to WUN_WG_BATCH levels, both side streams wait on it; the
-    // FLOP-heavy levels always flush at once) -- measured: 41 -> 26 stalls per step, but the delayed weight
-    // gradients lengthen the tail after the last input gradient by more (9.12 ms with batches of 1, 9.19-9.23 with
-    // 2-5), so the default stays one event per level.
+    // Weight gradients are queued and flushed one layer at a time: one event on the caller's stream per layer, both side
+    // streams wait on it.  (Batching several deep levels behind one event -- every event is a barrier packet that holds
+    // the dependent chain for ~7 us -- was measured in round 2: 41 -> 26 stalls per step, but the delayed weight gradients
+    // lengthen the tail after the last input gradient by more: 9.12 ms per step with one layer per event, 9.19 - 9.23 with 2 - 5.)
     struct PendingWgrad { WgradArgs w[2]; int n; const ConvLayer* cl; };
     std::vector<PendingWgrad> pend;
     // Early skip-window input gradients (context mode).  The input gradient of down level i is the transposed stride-2
@@ -1254,12 +1252,12 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
     // window of dz_dec[i-1], and the row-wide conv later ADDS inside the window (ConvArgs.acc_lo / acc_len) and stores
     // outside it: a + b == b + a, results are bit-identical to the old order.  Queued here, issued by the next flush
     // (whose event already orders the side streams behind the producing kernels: no extra packet on the chain).
-    // Default "deep": only the deep levels (input gradient = separate phase launches on a launch-latency-bound chain):
-    // same-box A/B 8.84 -> 8.82 ms.  "all" additionally moves the FLOP-heavy levels' window parts (8.98 vs 8.99: the
-    // end of the backward pass is throughput-bound, not chain-bound); "0" restores the old order.
+    // Only the deep levels (input gradient = separate phase launches on a launch-latency-bound chain): same-box A/B
+    // 8.84 -> 8.82 ms; moving the FLOP-heavy levels' window parts too changed nothing (8.98 vs 8.99: the end of the backward
+    // pass is throughput-bound, not chain-bound).  WUN_EARLY_WINDOW=0 restores the old order (other launch order: the
+    // tuning-table header records it).
     const char* ew_env = getenv("WUN_EARLY_WINDOW");
     const bool early_win = !same && !p->bf16 && !(ew_env != nullptr && ew_env[0] == '0');
-    const bool early_all = early_win && ew_env != nullptr && ew_env[0] == 'a';
     auto level_fused = [&](int i) {                                  // (the rule of the down-path loop below)
         const DownShape& d = p->dsh[i];
         ConvArgs f = conv_base(p);
@@ -1267,7 +1265,7 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
         f.flags = F_PHASE2; f.C0 = d.cout; f.B = p->B;
         return (d.cin & 3) == 0 && f.Tout >= 256 && conv_natural_wgs_phase2(f) >= 256;
     };
-    auto level_early = [&](int i) { return early_win && i > 0 && (early_all || !level_fused(i)); };
+    auto level_early = [&](int i) { return early_win && i > 0 && !level_fused(i); };
     if (early_win && p->win_ev.size() < (size_t)L) {
         p->win_ev.resize(L, nullptr);
         for (auto& e : p->win_ev)
@@ -1285,8 +1283,6 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
         set_dst0(a, ws, p->dz_dec[i - 1], d.cs, &p->dec[i - 1]);
         return a;
     };
-    static const int wg_batch = getenv("WUN_WG_BATCH") ? atoi(getenv("WUN_WG_BATCH")) : 1;
-    static const long long wg_batch_rows = getenv("WUN_WG_BATCH_ROWS") ? atoll(getenv("WUN_WG_BATCH_ROWS")) : 16384;
     auto flush_wgrads = [&]() -> int {
         if (pend.empty() && pend_win.empty()) return WUN_OK;
         if (s2 != s) {
@@ -1316,10 +1312,7 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
         for (int k = 0; k < n; ++k) q.w[k] = w[k];
         q.n = n; q.cl = &cl;
         pend.push_back(q);
-        long long rows = 0;
-        for (int k = 0; k < n; ++k) rows += (long long)w[k].B * w[k].Tq;
-        if (rows >= wg_batch_rows || (int)pend.size() >= wg_batch) return flush_wgrads();
-        return WUN_OK;
+        return flush_wgrads();
     };
 
     if (p->wt_ready) {
@@ -1528,9 +1521,8 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
                 set_dst0(f, ws, p->dz_dec[i - 1], 0, &p->dec[i - 1]);
                 const bool win_early = level_early(i) && !p->win_ev.empty();
                 if (win_early) {
-                    // the window part is already in dz_dec[i-1] (side stream): wait for it, add inside the window.  With
-                    // WUN_WG_BATCH > 1 its launch may still sit in the queue (win_ev[i] would be last step's record):
-                    // issue it now
+                    // the window part is already in dz_dec[i-1] (side stream): wait for it, add inside the window (a
+                    // launch still sitting in the queue -- win_ev[i] would be last step's record -- is issued now)
                     if (std::find(pend_win.begin(), pend_win.end(), i) != pend_win.end() && (rc = flush_wgrads())) return rc;
                     if (s2 != s) HIP_TRY(hipStreamWaitEvent(s, p->win_ev[(size_t)i], 0));
                     f.flags |= F_ACCUM; f.acc_lo = d.cs; f.acc_len = (unsigned)(d.tc + Kd - 1);
@@ -1603,7 +1595,6 @@ static std::string tune_header(const wun_plan* p, size_t ncf, size_t ncb, size_t
     // a non-default early-window mode changes the order of the backward conv launches: such tables only match themselves
     if (const char* ew = getenv("WUN_EARLY_WINDOW")) {
         if (ew[0] == '0') h += " ew=0";
-        else if (ew[0] == 'a') h += " ew=all";
     }
     return h;
 }

@@ -193,17 +193,12 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a, WgBfK g) {
     // per item: the 4 LDS destinations (element offsets from Xs; unit-invariant) in WRITE order -- write instruction k
     // stores position (k + rot) & 3 of the item, so the 32-byte rows of 4 neighbouring position groups differ mod 4
     // (positions before the image start, r < 0, go to a trash row behind the image)
-#ifdef WUN_BF_ABLATION
-    const bool norot = (a.ablate & 16) != 0;
-#else
-    constexpr bool norot = false;
-#endif
     const int trash = g.NCB * xsub;                       // 16 elements behind the last channel block (reserved by the launcher)
     unsigned xdst[WUN_WGB_XITP][2];
 #pragma unroll
     for (int i = 0; i < WUN_WGB_XITP; ++i) {
         const int pk = xpk[i];
-        const int cbl = (pk >> 24) & 15, pl = (pk >> 20) & 15, c4 = pk & 0xFFFFF, rot = norot ? 0 : (pk >> 28) & 3;
+        const int cbl = (pk >> 24) & 15, pl = (pk >> 20) & 15, c4 = pk & 0xFFFFF, rot = (pk >> 28) & 3;
         const int c = (cb0 + cbl) * 16 + 2 * pl;
         const int r0 = 4 * c4 - (c >= a.C0 ? delta1 : delta0);
         unsigned o[4];
@@ -247,7 +242,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a, WgBfK g) {
                         d[k] = in ? (d[k] & cm) : 0u;
                     }
                 }
-                const int rot = norot ? 0 : (pk >> 28) & 3;
+                const int rot = (pk >> 28) & 3;
                 if (rot & 1) { const unsigned t = d[0]; d[0] = d[1]; d[1] = d[2]; d[2] = d[3]; d[3] = t; }
                 if (rot & 2) { unsigned t = d[0]; d[0] = d[2]; d[2] = t; t = d[1]; d[1] = d[3]; d[3] = t; }
                 unsigned w0 = xdst[i][0], w1 = xdst[i][1];
@@ -279,13 +274,6 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a, WgBfK g) {
         (void)b;
     };
 
-    // diagnostic switches (WUN_WGB_ABL; uniform branches; builds with -DWUN_BF_ABLATION only): 1 no global loads,
-    // 2 no LDS stores, 4 no MFMA loop, 8 no barriers, 16 no write rotation
-#ifdef WUN_BF_ABLATION
-    const bool ab_noload = a.ablate & 1, ab_nostore = a.ablate & 2, ab_nomfma = a.ablate & 4, ab_nobar = a.ablate & 8;
-#else
-    constexpr bool ab_noload = false, ab_nostore = false, ab_nomfma = false, ab_nobar = false;
-#endif
     const int nunits = a.B * a.nQT;
     const int u0 = split * a.units_per_split;
     int u1 = u0 + a.units_per_split;
@@ -294,21 +282,15 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a, WgBfK g) {
     const int TKr = (g.TK + 31) & ~31;
     if (TKr != g.TK)
         for (int i = tid; i < NG * (TKr - g.TK); i += 256) Zs[(i / (TKr - g.TK)) * g.ZPe + g.TK + i % (TKr - g.TK)] = 0;
-    if (ab_noload) {
-#pragma unroll
-        for (int i = 0; i < WUN_WGB_XITP; ++i) { xra[i] = (u32x2){0u, 0u}; xrb[i] = xra[i]; }
-#pragma unroll
-        for (int i = 0; i < ZIT; ++i) zreg[i] = (u32x2){0u, 0u};
-    }
-    if (u0 < u1 && !ab_noload) load_unit(u0);
+    if (u0 < u1) load_unit(u0);
     for (int u = u0; u < u1; ++u) {
-        if (!ab_nobar) __syncthreads();
-        if (!ab_nostore) store_unit(u);
-        if (!ab_nobar) __syncthreads();
-        if (u + 1 < u1 && !ab_noload) load_unit(u + 1);
+        __syncthreads();
+        store_unit(u);
+        __syncthreads();
+        if (u + 1 < u1) load_unit(u + 1);
         const int qt = u % a.nQT;
         int nq = a.Tq - qt * g.TK; if (nq > g.TK) nq = g.TK;
-        const int nsteps = ab_nomfma ? 0 : (nq + 31) >> 5; // k-steps of 32 positions
+        const int nsteps = (nq + 31) >> 5; // k-steps of 32 positions
         for (int st = 0; st < nsteps; ++st) {
             bf16x8 bv[NW];
 #pragma unroll
@@ -522,7 +504,6 @@ static hipError_t wgrad_bf16_launch_t(WgradArgs a, const WgradBfGeom& g, hipStre
 
 hipError_t launch_wgrad_bf16(const WgradArgs& a, hipStream_t s) {
     if (!wgrad_bf16_supported(a) || !a.sbf) return hipErrorInvalidValue;     // bf16 rows in HBM (the operator entry point converts first)
-    if (const char* e = getenv("WUN_WGB_ABL")) const_cast<WgradArgs&>(a).ablate = atoi(e);
     if ((a.pitch0 & 3) || (a.bs0 & 3) || (reinterpret_cast<uintptr_t>(a.src0) & 15) || a.pitch0 < 4) return hipErrorInvalidValue;
     if (a.C1 > 0 && ((a.pitch1 & 3) || (a.bs1 & 3) || (reinterpret_cast<uintptr_t>(a.src1) & 15) || a.pitch1 < 4)) return hipErrorInvalidValue;
     if ((a.dzpitch & 3) || (a.dzbs & 3) || (reinterpret_cast<uintptr_t>(a.dz) & 15) || a.dzpitch < 4) return hipErrorInvalidValue;

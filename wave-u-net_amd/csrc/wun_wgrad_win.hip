@@ -64,14 +64,6 @@ __device__ __forceinline__ int win_xcd_block(int bid, int grid) {
 #define WUN_WIN_XIT 3
 #define WUN_WIN_ZIT 4
 
-#ifdef WUN_WIN_TRACE
-// diagnostic builds only (tools/win_trace.py): per workgroup and wave {100 MHz clock at entry / exit, HW_ID} + per unit
-// {loop top, data landed (barrier passed), DMA of the next unit issued, MFMAs done} shader-clock stamps
-#define WUN_WT_WGS 1024
-#define WUN_WT_UNITS 12
-#define WUN_WT_WORDS (4 + 4 * WUN_WT_UNITS)
-__device__ unsigned long long g_win_trace[WUN_WT_WGS * 8 * WUN_WT_WORDS];
-#endif
 
 struct WinParams {
     int RTW, CGW;        // row tiles x column groups per workgroup (waves = RTW * CGW)
@@ -401,14 +393,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((K15 ? NW <
     int u1 = u0 + a.units_per_split;
     if (u1 > nunits) u1 = nunits;
 
-#ifdef WUN_WIN_TRACE
-    const bool tr_on = lane == 0 && blockIdx.x < WUN_WT_WGS && wave < 8;
-    unsigned long long* trp = g_win_trace + ((size_t)(blockIdx.x < WUN_WT_WGS ? blockIdx.x : 0) * 8 + (wave & 7)) * WUN_WT_WORDS;
-    if (tr_on) { trp[0] = wall_clock64(); trp[1] = __builtin_readcyclecounter(); trp[3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)(u1 - u0) << 32); }
-#define WT_STAMP(k, i) do { if (tr_on && (k) < WUN_WT_UNITS) trp[4 + 4 * (k) + (i)] = __builtin_readcyclecounter(); } while (0)
-#else
 #define WT_STAMP(k, i) do { } while (0)
-#endif
     // (the unit loop is instantiated once per wave role: one MFMA stream, one register allocation problem each)
     auto unit_loop = [&](auto taps) __attribute__((always_inline)) {
         if (u0 >= u1) return;
@@ -441,9 +426,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((K15 ? NW <
     } else {
         unit_loop(WinTaps5{});
     }
-#ifdef WUN_WIN_TRACE
-    if (tr_on) trp[2] = wall_clock64();
-#endif
     if (!wave_live) return;
 
     // ---- store: final layout, one split = [K][Cin][Cout] followed by the bias row.  Lane (li, lg) holds rows 4 lg + r of
@@ -724,12 +706,3 @@ hipError_t launch_wgrad_win_reduce(const WgradArgs& a, const float* partial, int
 
 }  // namespace wun
 
-#ifdef WUN_WIN_TRACE
-extern "C" int wun_dbg_win_trace_read(unsigned long long* host, int nwords) {
-    const int cap = (int)(sizeof(wun::g_win_trace) / sizeof(unsigned long long));
-    if (nwords > cap) nwords = cap;
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(wun::g_win_trace), (size_t)nwords * sizeof(unsigned long long)) != hipSuccess) return -2;
-    return nwords;
-}
-#endif
