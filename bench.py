@@ -76,8 +76,8 @@ def usable_cores():
 
 # committed, READ-ONLY tuning tables per (named config, batch, dtype); never used as a writable cache
 PINNED_TUNE_TABLES = {
-    ("m1_context", 16, "f32"): os.path.join(ROOT, "profiles", "round4_tune_table.txt"),
-    ("baseline", 16, "f32"): os.path.join(ROOT, "profiles", "round4_tune_table_baseline.txt"),
+    ("m1_context", 16, "f32"): os.path.join(ROOT, "profiles", "round5_tune_table.txt"),
+    ("baseline", 16, "f32"): os.path.join(ROOT, "profiles", "round5_tune_table_baseline.txt"),
 }
 PINNED_TUNE_TABLE = PINNED_TUNE_TABLES[("m1_context", 16, "f32")]
 
@@ -163,7 +163,7 @@ def pmc_traffic(family, table_text):
     if that summary was collected with the very tuning table this run executes (its sha is stored
     beside the numbers); PMC counters cannot be collected from inside this process.  Else None."""
     import hashlib
-    path = os.path.join(ROOT, "profiles", "round4_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "round5_pmc_traffic.json")
     try:
         doc = json.load(open(path))
     except Exception:

@@ -66,11 +66,13 @@ typedef struct wun_config {
     int32_t num_sources;        /* len(source_names)                                          */
     int32_t num_channels;       /* 1 if mono_downmix else 2                                   */
     int32_t output_activation;  /* 0 = "tanh", 1 = "linear"                                   */
-    int32_t compute_dtype;      /* 0 = exact fp32 (v_mfma_f32_16x16x4_f32; the reference's arithmetic), */
-                                /* 1 = bf16 speed mode: conv / input-gradient operands rounded to bf16  */
-                                /*     on v_mfma_f32_16x16x32_bf16, fp32 accumulate; weights, Adam state,*/
-                                /*     activations in HBM, the audio-input conv and the head stay fp32; weight    */
-                                /*     gradients use bf16 operands too (launches with few positions stay fp32)   */
+    int32_t compute_dtype;      /* 0 = exact fp32 (v_mfma_f32_16x16x4_f32; the reference's arithmetic),                   */
+                                /* 1 = bf16 mode: every activation and activation-gradient tensor lives in HBM as bf16   */
+                                /*     (rounded once, by the epilogue that writes it), convs / input gradients / weight  */
+                                /*     gradients on v_mfma_f32_16x16x32_bf16 with fp32 accumulate; parameters, weight    */
+                                /*     gradients, Adam state, the audio and the head's d(pre-activation) stay fp32.      */
+                                /*     Needs num_initial_filters % 8 == 0 (else the plan is the exact-fp32 plan;        */
+                                /*     wun_plan_activation reports the element size).                                   */
     int32_t exclusive_streams;  /* scheduling hint, no effect on results.  1 = nothing else runs on this device  */
                                 /* beside the plan's calls: its side streams get the LOWEST queue priority (they  */
                                 /* fill the gaps of the dependent chain on the caller's stream, ~1 % per step).   */
@@ -258,15 +260,16 @@ int wun_op_set_wgrad_win(int on);
  * shapes fail with WUN_ERR_UNSUPPORTED. */
 int wun_op_set_wgrad_narrow(int on);
 
-/* The bf16 speed mode's conv as a single operator (wun_op_conv1d semantics, Cin >= 8, K <= 15): operands
- * are rounded to bf16 (nearest-even), products accumulate in fp32.  scratch: device floats, at least
+/* The bf16 mode's conv as a single operator (wun_op_conv1d semantics, Cin >= 8, K <= 15): x and w
+ * are rounded to bf16 (nearest-even; x into a temporary bf16 copy -- the kernel reads bf16 rows), products accumulate
+ * in fp32, y is stored as fp32.  scratch: device floats, at least
  * wun_op_conv1d_bf16_scratch(cin, cout, k) (packed bf16 weight image).  Synchronises the stream. */
 int64_t wun_op_conv1d_bf16_scratch(int cin, int cout, int k);
 int wun_op_conv1d_bf16(const float* x, const float* w, const float* bias, float* y, float* scratch,
                        int batch, int cin, int cout, int k, int t_in, int t_out, int stride, int pad_left,
                        int lrelu, void* stream);
 
-/* Input gradient in the bf16 speed mode (wun_op_conv1d_dgrad semantics; stride 2 = the fused two-phase transposed
+/* Input gradient in the bf16 mode (wun_op_conv1d_dgrad semantics; stride 2 = the fused two-phase transposed
  * conv, pad_left 0 and cin % 4 == 0).  scratch: device floats, >= wun_op_conv1d_dgrad_bf16_scratch(cin, cout, k).
  * Synchronises the stream. */
 int64_t wun_op_conv1d_dgrad_bf16_scratch(int cin, int cout, int k);

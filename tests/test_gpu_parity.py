@@ -837,13 +837,13 @@ def test_tuned_plan_error_is_the_leaky_relu_sign_floor(lib):
 def test_benchmarked_configuration_b16_tuned_vs_oracle(lib):
     """EXACTLY what bench.py times -- BASELINE.json configs[1]: M1 with context, batch 16,
     147443 -> 16389 samples, the Trainer's seed-1337 weights, the synthetic_source(seed 1337) batch
-    and the tilings bench.py runs (the committed table profiles/round4_tune_table.txt, handed to
+    and the tilings bench.py runs (the committed table profiles/round5_tune_table.txt, handed to
     Trainer.tune as read-only text, when it matches this build; a fresh wun_plan_tune otherwise) -- compared element
     by element with the FLOAT64 oracle: outputs, loss and all 54 gradient tensors of the whole batch
     (the oracle runs one excerpt at a time and averages: the loss is a mean over excerpts)."""
     from wave_u_net_amd.training import Trainer, synthetic_source
     cfg = wun.get_config("m1_context")
-    table = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "round4_tune_table.txt")
+    table = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "round5_tune_table.txt")
     text = open(table).read() if os.path.exists(table) else None
     before = text
     tr = Trainer(cfg, batch_size=16)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Copy the artefacts of `tools/profile_round.sh <tag>` from gpurun_out/ (scratch) into profiles/ (tracked), putting a
 header line on the two rocprofv3 kernel-stats CSVs that says which command they profile and how many training steps
-they contain (counted from the adam_kernel calls).   usage: python tools/collect_profiles.py round4"""
+they contain (counted from the adam_kernel calls).   usage: python tools/collect_profiles.py round5"""
 import csv
 import glob
 import json

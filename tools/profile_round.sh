@@ -7,7 +7,7 @@ tag=${1:-round}
 R=$PWD
 mkdir -p gpurun_out
 # tilings: bench.py imports the committed pinned table of the config by itself (read-only); PINNED=0 -> fresh tuning
-PIN=$R/profiles/round4_tune_table.txt
+PIN=$R/profiles/round5_tune_table.txt
 if [ "${PINNED:-1}" != 1 ]; then
     export WUN_TUNE_CACHE=$R/gpurun_out/${tag}_tune_table.txt
     [ "${KEEP_TUNE:-0}" = 1 ] || rm -f $WUN_TUNE_CACHE
@@ -52,6 +52,6 @@ if [ "${CFGS:-1}" = 1 ]; then
     done
     python bench.py --dtype bf16 --no-cpu-baseline > gpurun_out/${tag}_cfg_m1_context_bf16.json 2> gpurun_out/${tag}_cfg_m1_context_bf16.err
     WUN_NO_TUNE=1 python bench.py --config deep_l16_f48 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_cfg_deep_f32.json 2> gpurun_out/${tag}_cfg_deep_f32.err
-    WUN_NO_TUNE=1 python bench.py --config deep_l16_f48 --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_cfg_deep_bf16.json 2> gpurun_out/${tag}_cfg_deep_bf16.err
+    python bench.py --config deep_l16_f48 --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_cfg_deep_bf16.json 2> gpurun_out/${tag}_cfg_deep_bf16.err   # (autotuned: the bf16 tile menu is small)
     for f in gpurun_out/${tag}_cfg_*.json; do echo "$f: $(cut -c1-200 $f)"; done
 fi
