@@ -150,3 +150,39 @@ def test_branch_pinned_leaky_relu_is_the_free_oracle_on_its_own_branches(name):
     pins["up0"] = (pos, known)
     _, g2, _ = wt.chunked_train_step(cfg, params, mix, targets, dtype=torch.float64, chunk=1, pins=pins)
     assert any((a - b).abs().max().item() > 1e-9 * a.abs().max().item() for a, b in zip(g0, g2))
+
+
+@pytest.mark.parametrize("name", ["baseline_small", "baseline_diff_small", "baseline_context_small", "baseline_stereo_small",
+                                  "full_small", "full_multi_small", "learned_same_small", "odd_filters_small",
+                                  "odd_filters_same_small", "input_filter_mismatch_small", "filter1_context_small",
+                                  "baseline_comparison_small"])
+def test_second_independent_backward_agrees_with_autograd(name):
+    """oracle/backward_np.py: the same graph in numpy float64 with every adjoint written out by hand (no autograd, tap loops
+    instead of library convolutions) against torch autograd over oracle/waveunet_torch.py -- two independent backward
+    passes (Weak #3: "backward parity rests on one implementation").  Loss to 1e-13 relative, every
+    gradient tensor to 1e-10 of its largest element; both must also hold with an exact-zero pre-activation in play (a
+    silent excerpt with zero biases: the LeakyReLU tie, TensorFlow's 0.2)."""
+    from oracle import backward_np
+    case = GOLDEN_CASES[name]
+    cfg = _cfg(case)
+    for silent in (False, True):
+        params = golden_params(cfg, case["seed"])
+        if silent:
+            params = [(n, (np.zeros_like(v) if n.endswith("/bias") else v)) for n, v in params]
+        B = 2
+        i, o = shapes.get_padding(cfg, [B, case["frames"], 0])
+        mix, targets = wt.synthetic_batch(cfg, B, i[1], o[1], seed=case["seed"] + 500)
+        if silent:
+            mix = mix.copy(); mix[0] = 0.0
+            targets = {k: v.copy() for k, v in targets.items()}
+            for k in targets:
+                targets[k][0] = 0.0
+        tp = wt.params_to_torch(params, torch.float64, requires_grad=True)
+        oloss, ograds = wt.train_step(cfg, tp, torch.tensor(mix, dtype=torch.float64),
+                                      {k: torch.tensor(v, dtype=torch.float64) for k, v in targets.items()})
+        nloss, ngrads = backward_np.loss_and_gradients(cfg, params, mix, targets)
+        assert abs(nloss - oloss.item()) <= 1e-13 * max(1.0, abs(oloss.item())), (nloss, oloss.item())
+        for (n, _), og, ng in zip(tp, ograds, ngrads):
+            og = og.numpy()
+            assert og.shape == ng.shape, n
+            assert np.abs(og - ng).max() <= 1e-10 * max(np.abs(og).max(), 1e-30), (n, silent, np.abs(og - ng).max(), np.abs(og).max())
