@@ -2269,6 +2269,85 @@ hipError_t launch_upsample_bwd(const UpsampleBwdArgs& a, hipStream_t s) {
 __device__ __forceinline__ int head_block_floats(const HeadArgs& a) { return a.Ko * (a.C + a.F) * a.C + a.C; }
 
 // (FT: element type of the feature map -- float, or bf16_t in the bf16 mode)
+// one output position (b, t) of every source: hw = the heads' weights in LDS, blk = floats per source
+template <typename FT>
+__device__ __forceinline__ void head_fwd_pos(const HeadArgs& a, const float* hw, const FT* featp, int b, int t) {
+    const int Cin = a.C + a.F;
+    const int blk = a.Ko * Cin * a.C + a.C;
+    float acc[WUN_MAX_HEAD_ACC];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            acc[s * 2 + c] = (s < a.Sh && c < a.C) ? hw[s * blk + a.Ko * Cin * a.C + c] : 0.f;
+    if (a.Ko == 1 && t - a.padl >= 0 && t - a.padl < a.Tfeat) {
+        // 1-tap head: the feature rows eight at a time, loads first (the generic loop is one dependent load per channel)
+        const int tf = t - a.padl;
+        for (int ci = 0; ci < a.C; ++ci) {
+            const float xv = a.mix_ncw[(long long)b * a.mbs + (long long)ci * a.mpitch + a.moff_feat + tf];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    if (s < a.Sh && c < a.C) acc[s * 2 + c] += hw[s * blk + ci * a.C + c] * xv;
+        }
+        const FT* __restrict__ fr = featp + (long long)b * a.fbs + tf;
+        for (int f0 = 0; f0 < a.F; f0 += 8) {
+            float xf[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xf[j] = f0 + j < a.F ? ld1<FT>(fr, (long long)(f0 + j) * a.fpitch) : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (f0 + j < a.F) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+                            if (s < a.Sh && c < a.C) acc[s * 2 + c] += hw[s * blk + (a.C + f0 + j) * a.C + c] * xf[j];
+                }
+        }
+    } else
+    for (int k = 0; k < a.Ko; ++k) {
+        const int tf = t + k - a.padl;
+        if (tf < 0 || tf >= a.Tfeat) continue;
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float xv = (ci < a.C)
+                ? a.mix_ncw[(long long)b * a.mbs + (long long)ci * a.mpitch + a.moff_feat + tf]
+                : ld1<FT>(featp, (long long)b * a.fbs + (long long)(ci - a.C) * a.fpitch + tf);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    if (s < a.Sh && c < a.C)
+                        acc[s * 2 + c] += hw[s * blk + (k * Cin + ci) * a.C + c] * xv;
+        }
+    }
+    float tot0 = 0.f, tot1 = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (s < a.Sh && c < a.C) {
+                float v = acc[s * 2 + c];
+                if (a.tanh_act) v = tanhf(v);
+                else if (!a.training) v = fminf(fmaxf(v, -1.f), 1.f);
+                a.out[(((long long)s * a.B + b) * a.Tout + t) * a.C + c] = v;
+                if (c == 0) tot0 += v; else tot1 += v;
+            }
+        }
+    if (a.difference) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (c < a.C) {
+                float v = a.mix_ncw[(long long)b * a.mbs + (long long)c * a.mpitch + a.moff_diff + t] -
+                          (c == 0 ? tot0 : tot1);
+                if (!a.training) v = fminf(fmaxf(v, -1.f), 1.f);
+                a.out[(((long long)(a.S - 1) * a.B + b) * a.Tout + t) * a.C + c] = v;
+            }
+        }
+    }
+}
+
 template <typename FT>
 __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a, long long h0, long long h1,
                                                        long long h2, long long h3) {
@@ -2279,86 +2358,192 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a, long long h0,
     for (int s = 0; s < a.Sh; ++s)
         for (int i = threadIdx.x; i < blk; i += 256) hw[s * blk + i] = a.Wh[hoff[s] + i];
     __syncthreads();
-    const int Cin = a.C + a.F;
     const long long total = (long long)a.B * a.Tout;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * 256) {
         const int t = (int)(idx % a.Tout), b = (int)(idx / a.Tout);
-        float acc[WUN_MAX_HEAD_ACC];
+        head_fwd_pos<FT>(a, hw, featp, b, t);
+    }
+}
+
+
+// 1-tap head (every shipped config), FOUR consecutive positions per thread: a feature row is one 16-byte (fp32) / 8-byte
+// (bf16) load per thread instead of four element loads in four threads, the per-source weights are read from LDS once
+// per four positions, the outputs of a source are one (mono) or two (stereo) 16-byte stores.  Same arithmetic and the same
+// summation order per element as head_fwd_kernel's 1-tap path: bit-identical outputs.  Tout % 4 tail positions, an
+// unaligned feature map or Ko > 1 take head_fwd_kernel.  (The [S][B][Tout][C] output rows start at (s B + b) Tout C floats: only
+// dword-aligned for odd Tout -- the output vectors are stored through a 4-byte-aligned vector type.)
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+template <typename FT>
+__global__ __launch_bounds__(256) void head_fwd4_kernel(HeadArgs a, long long h0, long long h1, long long h2, long long h3) {
+    extern __shared__ float hw[];
+    const FT* const featp = reinterpret_cast<const FT*>(a.feat);
+    const long long hoff[4] = {h0, h1, h2, h3};
+    const int Cin = a.C + a.F;
+    const int blk = Cin * a.C + a.C;                       // Ko == 1
+    for (int s = 0; s < a.Sh; ++s)
+        for (int i = threadIdx.x; i < blk; i += 256) hw[s * blk + i] = a.Wh[hoff[s] + i];
+    __syncthreads();
+    const int nq = a.Tout >> 2;                            // whole groups of four positions per excerpt
+    const long long total = (long long)a.B * nq;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int qi = (int)(idx % nq), b = (int)(idx / nq);
+        const int t = 4 * qi;                              // padl == 0: feature position == output position
+        float acc[4][WUN_MAX_HEAD_ACC];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    acc[r][s * 2 + c] = (s < a.Sh && c < a.C) ? hw[s * blk + Cin * a.C + c] : 0.f;
+        for (int ci = 0; ci < a.C; ++ci) {
+            const float* mr = a.mix_ncw + (long long)b * a.mbs + (long long)ci * a.mpitch + a.moff_feat + t;
+            const float xv[4] = {mr[0], mr[1], mr[2], mr[3]};
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    if (s < a.Sh && c < a.C) {
+                        const float w = hw[s * blk + ci * a.C + c];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[r][s * 2 + c] += w * xv[r];
+                    }
+        }
+        const FT* __restrict__ fr = featp + (long long)b * a.fbs + t;
+        for (int f0 = 0; f0 < a.F; f0 += 4) {
+            f32x4 xf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xf[j] = f0 + j < a.F ? ld4<FT>(fr, (long long)(f0 + j) * a.fpitch) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (f0 + j < a.F) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+                            if (s < a.Sh && c < a.C) {
+                                const float w = hw[s * blk + (a.C + f0 + j) * a.C + c];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) acc[r][s * 2 + c] += w * xf[j][r];
+                            }
+                }
+        }
+        float tot[4][2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { tot[r][0] = 0.f; tot[r][1] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s < a.Sh) {
+                float v[4][2];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        float x = acc[r][s * 2 + c];
+                        if (a.tanh_act) x = tanhf(x);
+                        else if (!a.training) x = fminf(fmaxf(x, -1.f), 1.f);
+                        v[r][c] = x;
+                        if (c < a.C) tot[r][c] += x;
+                    }
+                float* op = a.out + (((long long)s * a.B + b) * a.Tout + t) * a.C;
+                if (a.C == 1) {
+                    *reinterpret_cast<f32x4u*>(op) = (f32x4u){v[0][0], v[1][0], v[2][0], v[3][0]};
+                } else {
+                    *reinterpret_cast<f32x4u*>(op) = (f32x4u){v[0][0], v[0][1], v[1][0], v[1][1]};
+                    *reinterpret_cast<f32x4u*>(op + 4) = (f32x4u){v[2][0], v[2][1], v[3][0], v[3][1]};
+                }
+            }
+        }
+        if (a.difference) {
+            float v[4][2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                if (c < a.C) {
+                    const float* mr = a.mix_ncw + (long long)b * a.mbs + (long long)c * a.mpitch + a.moff_diff + t;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float x = mr[r] - tot[r][c];
+                        if (!a.training) x = fminf(fmaxf(x, -1.f), 1.f);
+                        v[r][c] = x;
+                    }
+                }
+            float* op = a.out + (((long long)(a.S - 1) * a.B + b) * a.Tout + t) * a.C;
+            if (a.C == 1) {
+                *reinterpret_cast<f32x4u*>(op) = (f32x4u){v[0][0], v[1][0], v[2][0], v[3][0]};
+            } else {
+                *reinterpret_cast<f32x4u*>(op) = (f32x4u){v[0][0], v[0][1], v[1][0], v[1][1]};
+                *reinterpret_cast<f32x4u*>(op + 4) = (f32x4u){v[2][0], v[2][1], v[3][0], v[3][1]};
+            }
+        }
+    }
+    // the Tout % 4 last positions of every excerpt: one position per thread, the generic path
+    const int tail = a.Tout & 3;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < (long long)a.B * tail; idx += (long long)gridDim.x * 256)
+        head_fwd_pos<FT>(a, hw, featp, (int)(idx / tail), 4 * nq + (int)(idx % tail));
+}
+
+// ... and the same for d(feature map): the Sh * C gradient samples of four positions are loaded once (16-byte loads), each
+// feature row is one vector load (the LeakyReLU mask) and one vector store.  Bit-identical to head_dfeat_kernel's 1-tap path.
+template <typename FT>
+__global__ __launch_bounds__(256) void head_dfeat4_kernel(HeadArgs a, long long h0, long long h1, long long h2, long long h3) {
+    extern __shared__ float hw[];
+    const FT* const featp = reinterpret_cast<const FT*>(a.feat);
+    FT* const dzp = reinterpret_cast<FT*>(a.dzfeat);
+    const long long hoff[4] = {h0, h1, h2, h3};
+    const int Cin = a.C + a.F;
+    const int blk = Cin * a.C + a.C;
+    for (int s = 0; s < a.Sh; ++s)
+        for (int i = threadIdx.x; i < blk; i += 256) hw[s * blk + i] = a.Wh[hoff[s] + i];
+    __syncthreads();
+    const int nq = a.Tfeat >> 2;
+    const long long total = (long long)a.B * nq;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int qi = (int)(idx % nq), b = (int)(idx / nq);
+        const int u = 4 * qi;                              // padl == 0 and Tfeat == Tout (1-tap head)
+        f32x4 dp[WUN_MAX_HEAD_ACC];
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int c = 0; c < 2; ++c)
-                acc[s * 2 + c] = (s < a.Sh && c < a.C) ? hw[s * blk + a.Ko * Cin * a.C + c] : 0.f;
-        if (a.Ko == 1 && t - a.padl >= 0 && t - a.padl < a.Tfeat) {
-            // 1-tap head: the feature rows eight at a time, loads first (the generic loop is one dependent load per channel)
-            const int tf = t - a.padl;
-            for (int ci = 0; ci < a.C; ++ci) {
-                const float xv = a.mix_ncw[(long long)b * a.mbs + (long long)ci * a.mpitch + a.moff_feat + tf];
+                dp[s * 2 + c] = (s < a.Sh && c < a.C)
+                    ? *reinterpret_cast<const f32x4*>(a.dpre + (long long)s * a.dps + (long long)b * a.dpbs + (long long)c * a.dppitch + u)
+                    : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const FT* __restrict__ fr = featp + (long long)b * a.fbs + u;
+        FT* __restrict__ dr = dzp + (long long)b * a.fbs + u;
+        for (int f0 = 0; f0 < a.F; f0 += 4) {
+            f32x4 xf[4], g[4];
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+            for (int j = 0; j < 4; ++j) xf[j] = f0 + j < a.F ? ld4<FT>(fr, (long long)(f0 + j) * a.fpitch) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int c = 0; c < 2; ++c)
-                        if (s < a.Sh && c < a.C) acc[s * 2 + c] += hw[s * blk + ci * a.C + c] * xv;
-            }
-            const FT* __restrict__ fr = featp + (long long)b * a.fbs + tf;
-            for (int f0 = 0; f0 < a.F; f0 += 8) {
-                float xf[8];
+            for (int j = 0; j < 4; ++j) {
+                g[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (f0 + j < a.F) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) xf[j] = f0 + j < a.F ? ld1<FT>(fr, (long long)(f0 + j) * a.fpitch) : 0.f;
+                    for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (f0 + j < a.F) {
+                        for (int c = 0; c < 2; ++c)
+                            if (s < a.Sh && c < a.C) {
+                                const float w = hw[s * blk + (a.C + f0 + j) * a.C + c];
 #pragma unroll
-                        for (int s = 0; s < 4; ++s)
-#pragma unroll
-                            for (int c = 0; c < 2; ++c)
-                                if (s < a.Sh && c < a.C) acc[s * 2 + c] += hw[s * blk + (a.C + f0 + j) * a.C + c] * xf[j];
-                    }
-            }
-        } else
-        for (int k = 0; k < a.Ko; ++k) {
-            const int tf = t + k - a.padl;
-            if (tf < 0 || tf >= a.Tfeat) continue;
-            for (int ci = 0; ci < Cin; ++ci) {
-                const float xv = (ci < a.C)
-                    ? a.mix_ncw[(long long)b * a.mbs + (long long)ci * a.mpitch + a.moff_feat + tf]
-                    : ld1<FT>(featp, (long long)b * a.fbs + (long long)(ci - a.C) * a.fpitch + tf);
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int c = 0; c < 2; ++c)
-                        if (s < a.Sh && c < a.C)
-                            acc[s * 2 + c] += hw[s * blk + (k * Cin + ci) * a.C + c] * xv;
-            }
-        }
-        float tot0 = 0.f, tot1 = 0.f;
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                if (s < a.Sh && c < a.C) {
-                    float v = acc[s * 2 + c];
-                    if (a.tanh_act) v = tanhf(v);
-                    else if (!a.training) v = fminf(fmaxf(v, -1.f), 1.f);
-                    a.out[(((long long)s * a.B + b) * a.Tout + t) * a.C + c] = v;
-                    if (c == 0) tot0 += v; else tot1 += v;
+                                for (int r = 0; r < 4; ++r) g[j][r] += w * dp[s * 2 + c][r];
+                            }
                 }
             }
-        if (a.difference) {
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                if (c < a.C) {
-                    float v = a.mix_ncw[(long long)b * a.mbs + (long long)c * a.mpitch + a.moff_diff + t] -
-                              (c == 0 ? tot0 : tot1);
-                    if (!a.training) v = fminf(fmaxf(v, -1.f), 1.f);
-                    a.out[(((long long)(a.S - 1) * a.B + b) * a.Tout + t) * a.C + c] = v;
+            for (int j = 0; j < 4; ++j)
+                if (f0 + j < a.F) {
+                    f32x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = g[j][r] * ((xf[j][r] > 0.f) ? 1.f : 0.2f);
+                    st4<FT>(dr, (long long)(f0 + j) * a.fpitch, o);
                 }
-            }
         }
     }
+    const int tail = a.Tfeat & 3;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < (long long)a.B * tail; idx += (long long)gridDim.x * 256)
+        head_dfeat_pos<FT>(a, hw, featp, dzp, (int)(idx / tail), 4 * nq + (int)(idx % tail));
 }
-
 
 // loss partials + dpre (gradient wrt the pre-activation of each head conv output)
 __global__ __launch_bounds__(256) void head_bwd_kernel(HeadArgs a) {
@@ -2395,6 +2580,62 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadArgs a) {
 }
 
 // dzfeat[b][f][u] = lrelu'(feat) * sum_{k,s,c} W[s][k][C+f][c] * dpre[s][b][c][u - k + padl]
+// one feature-map position (b, u), all F channels
+template <typename FT>
+__device__ __forceinline__ void head_dfeat_pos(const HeadArgs& a, const float* hw, const FT* featp, FT* dzp, int b, int u) {
+    const int Cin = a.C + a.F;
+    const int blk = a.Ko * Cin * a.C + a.C;
+    if (a.Ko == 1) {
+        // 1-tap head (every shipped config): the Sh * C gradient samples of this position are loaded once, the
+        // feature rows four at a time with all loads issued before the first store (the generic loop below re-reads
+        // the gradient per feature channel and serialises load -> store per channel: 25 us for 27 MB)
+        const int t = u + a.padl;
+        float dp[WUN_MAX_HEAD_ACC];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                dp[s * 2 + c] = (s < a.Sh && c < a.C && t >= 0 && t < a.Tout)
+                    ? a.dpre[(long long)s * a.dps + (long long)b * a.dpbs + (long long)c * a.dppitch + t] : 0.f;
+        const FT* __restrict__ fr = featp + (long long)b * a.fbs + u;
+        FT* __restrict__ dr = dzp + (long long)b * a.fbs + u;
+        for (int f0 = 0; f0 < a.F; f0 += 4) {
+            float xf[4], g[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xf[j] = f0 + j < a.F ? ld1<FT>(fr, (long long)(f0 + j) * a.fpitch) : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                g[j] = 0.f;
+                if (f0 + j < a.F) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+                            if (s < a.Sh && c < a.C) g[j] += hw[s * blk + (a.C + f0 + j) * a.C + c] * dp[s * 2 + c];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (f0 + j < a.F) st1<FT>(dr, (long long)(f0 + j) * a.fpitch, g[j] * ((xf[j] > 0.f) ? 1.f : 0.2f));
+        }
+        return;
+    }
+    for (int f = 0; f < a.F; ++f) {
+        float g = 0.f;
+        for (int k = 0; k < a.Ko; ++k) {
+            const int t = u - k + a.padl;
+            if (t < 0 || t >= a.Tout) continue;
+            for (int s = 0; s < a.Sh; ++s)
+                for (int c = 0; c < a.C; ++c)
+                    g += hw[s * blk + (k * Cin + a.C + f) * a.C + c] *
+                         a.dpre[(long long)s * a.dps + (long long)b * a.dpbs + (long long)c * a.dppitch + t];
+        }
+        const long long fi = (long long)b * a.fbs + (long long)f * a.fpitch + u;
+        g *= (ld1<FT>(featp, fi) > 0.f) ? 1.f : 0.2f;
+        st1<FT>(dzp, fi, g);
+    }
+}
+
 template <typename FT>
 __global__ __launch_bounds__(256) void head_dfeat_kernel(HeadArgs a, long long h0, long long h1,
                                                          long long h2, long long h3) {
@@ -2406,60 +2647,11 @@ __global__ __launch_bounds__(256) void head_dfeat_kernel(HeadArgs a, long long h
     for (int s = 0; s < a.Sh; ++s)
         for (int i = threadIdx.x; i < blk; i += 256) hw[s * blk + i] = a.Wh[hoff[s] + i];
     __syncthreads();
-    const int Cin = a.C + a.F;
     const long long total = (long long)a.B * a.Tfeat;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * 256) {
         const int u = (int)(idx % a.Tfeat), b = (int)(idx / a.Tfeat);
-        if (a.Ko == 1) {
-            // 1-tap head (every shipped config): the Sh * C gradient samples of this position are loaded once, the
-            // feature rows four at a time with all loads issued before the first store (the generic loop below re-reads
-            // the gradient per feature channel and serialises load -> store per channel: 25 us for 27 MB)
-            const int t = u + a.padl;
-            float dp[WUN_MAX_HEAD_ACC];
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-                    dp[s * 2 + c] = (s < a.Sh && c < a.C && t >= 0 && t < a.Tout)
-                        ? a.dpre[(long long)s * a.dps + (long long)b * a.dpbs + (long long)c * a.dppitch + t] : 0.f;
-            const FT* __restrict__ fr = featp + (long long)b * a.fbs + u;
-            FT* __restrict__ dr = dzp + (long long)b * a.fbs + u;
-            for (int f0 = 0; f0 < a.F; f0 += 4) {
-                float xf[4], g[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) xf[j] = f0 + j < a.F ? ld1<FT>(fr, (long long)(f0 + j) * a.fpitch) : 0.f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    g[j] = 0.f;
-                    if (f0 + j < a.F) {
-#pragma unroll
-                        for (int s = 0; s < 4; ++s)
-#pragma unroll
-                            for (int c = 0; c < 2; ++c)
-                                if (s < a.Sh && c < a.C) g[j] += hw[s * blk + (a.C + f0 + j) * a.C + c] * dp[s * 2 + c];
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (f0 + j < a.F) st1<FT>(dr, (long long)(f0 + j) * a.fpitch, g[j] * ((xf[j] > 0.f) ? 1.f : 0.2f));
-            }
-            continue;
-        }
-        for (int f = 0; f < a.F; ++f) {
-            float g = 0.f;
-            for (int k = 0; k < a.Ko; ++k) {
-                const int t = u - k + a.padl;
-                if (t < 0 || t >= a.Tout) continue;
-                for (int s = 0; s < a.Sh; ++s)
-                    for (int c = 0; c < a.C; ++c)
-                        g += hw[s * blk + (k * Cin + a.C + f) * a.C + c] *
-                             a.dpre[(long long)s * a.dps + (long long)b * a.dpbs + (long long)c * a.dppitch + t];
-            }
-            const long long fi = (long long)b * a.fbs + (long long)f * a.fpitch + u;
-            g *= (ld1<FT>(featp, fi) > 0.f) ? 1.f : 0.2f;
-            st1<FT>(dzp, fi, g);
-        }
+        head_dfeat_pos<FT>(a, hw, featp, dzp, b, u);
     }
 }
 
@@ -2688,6 +2880,13 @@ static size_t head_lds(const HeadArgs& a) {
     return sizeof(float) * (size_t)a.Sh * (a.Ko * (a.C + a.F) * a.C + a.C);
 }
 
+// the four-positions-per-thread forms: 1-tap head without padding (feature position == output position), feature rows
+// and output rows aligned for 16-byte (fp32) / 8-byte (bf16) vectors
+static bool head_vec4_ok(const HeadArgs& a) {
+    return a.Ko == 1 && a.padl == 0 && a.Tfeat == a.Tout && a.Tout >= 4 && (a.fpitch & 3) == 0 && (a.fbs & 3) == 0 &&
+           (reinterpret_cast<uintptr_t>(a.feat) & 15) == 0;
+}
+
 hipError_t launch_head_fwd_off(const HeadArgs& a, const long long* hoff, hipStream_t s) {
     const long long total = (long long)a.B * a.Tout;
     long long blocks = (total + 255) / 256;
@@ -2695,6 +2894,14 @@ hipError_t launch_head_fwd_off(const HeadArgs& a, const long long* hoff, hipStre
     // feature map + mix window read once, all sources written
     const double fb = a.featbf ? 2.0 : 4.0;
     ProfScope ps("head_fwd_kernel", 0.0, s, "", (double)a.B * ((double)a.Tfeat * (fb * a.F + 4.0 * a.C) + 4.0 * (double)a.Tout * a.S * a.C));
+    if (head_vec4_ok(a)) {
+        long long b4 = ((long long)a.B * (a.Tout >> 2) + 255) / 256;
+        if (b4 > 4096) b4 = 4096;
+        if (b4 < 1) b4 = 1;
+        if (a.featbf) hipLaunchKernelGGL(head_fwd4_kernel<bf16_t>, dim3((unsigned)b4), dim3(256), head_lds(a), s, a, hoff[0], hoff[1], hoff[2], hoff[3]);
+        else hipLaunchKernelGGL(head_fwd4_kernel<float>, dim3((unsigned)b4), dim3(256), head_lds(a), s, a, hoff[0], hoff[1], hoff[2], hoff[3]);
+        return hipGetLastError();
+    }
     if (a.featbf) hipLaunchKernelGGL(head_fwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), head_lds(a), s, a, hoff[0], hoff[1], hoff[2], hoff[3]);
     else hipLaunchKernelGGL(head_fwd_kernel<float>, dim3((unsigned)blocks), dim3(256), head_lds(a), s, a, hoff[0], hoff[1], hoff[2], hoff[3]);
     return hipGetLastError();
@@ -2720,6 +2927,15 @@ hipError_t launch_head_bwd_off(const HeadArgs& a, const long long* hoff, hipStre
     const long long total = (long long)a.B * a.Tfeat;
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
+    if (head_vec4_ok(a) && (a.dppitch & 3) == 0 && (a.dpbs & 3) == 0 && (a.dps & 3) == 0 && (reinterpret_cast<uintptr_t>(a.dpre) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(a.dzfeat) & 15) == 0) {
+        long long b4 = ((long long)a.B * (a.Tfeat >> 2) + 255) / 256;
+        if (b4 > 4096) b4 = 4096;
+        if (b4 < 1) b4 = 1;
+        if (a.featbf) hipLaunchKernelGGL(head_dfeat4_kernel<bf16_t>, dim3((unsigned)b4), dim3(256), head_lds(a), s, a, hoff[0], hoff[1], hoff[2], hoff[3]);
+        else hipLaunchKernelGGL(head_dfeat4_kernel<float>, dim3((unsigned)b4), dim3(256), head_lds(a), s, a, hoff[0], hoff[1], hoff[2], hoff[3]);
+        return hipGetLastError();
+    }
     if (a.featbf) hipLaunchKernelGGL(head_dfeat_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), head_lds(a), s, a, hoff[0], hoff[1], hoff[2], hoff[3]);
     else hipLaunchKernelGGL(head_dfeat_kernel<float>, dim3((unsigned)blocks), dim3(256), head_lds(a), s, a, hoff[0], hoff[1], hoff[2], hoff[3]);
     return hipGetLastError();
