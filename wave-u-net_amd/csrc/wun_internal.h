@@ -137,6 +137,7 @@ struct NarrowWgradArgs {
     float* partial;      // [splits][(KW*Ctot + 1) * N]
     int split_base, nsplit, units_per_split, nQT;
     int et;              // element types: bit 0 src0, bit 1 src1, bit 2 dz stored as bf16 (geometry in elements)
+    int nrow0;           // streaming form: first dz row of this launch (set by the launcher)
 };
 
 struct ConvChoice { int variant; int ksplit; };

@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(NarrowWgradArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Streaming form for ONE input channel (the mono audio-input conv: dz is 24 rows of up to 73715 positions, x one row):
+// Streaming form for ONE or TWO input channels (the mono / stereo audio-input conv: dz is 24 .. 48 rows of up to 73715 positions
+// -- 24 rows per launch --, x one or two rows; round 5: the stereo form, 31 accumulators per dz row):
 // no LDS, no barrier in the unit loop.  A unit is 256 output positions; lane l of every wave owns positions
 // q0 + 4 l .. + 3, wave w the dz rows [w NPW, (w + 1) NPW).  Per unit a lane loads its dz quads straight from global
 // memory (one 16-byte load per row: a wave instruction reads 1 KiB contiguous) and its x window of 3 SI + KT samples
@@ -162,19 +163,21 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(NarrowWgradArgs a) {
 // row into KT + 1 accumulators per row.  At the end the 64 lanes of a wave are summed per accumulator with a fixed DPP
 // tree (row_shr 1, 2, 4, 8, then the four row totals in order) and the workgroup writes one partial vector -- the layout
 // narrow_wgrad_reduce_kernel expects.
-template <int KT, int SI, int NPW, bool PF, typename ZT>
+template <int KT, int SI, int NPW, bool PF, typename ZT, int CIN>
 __global__ __launch_bounds__(64 * (24 / NPW)) void narrow_stream_kernel(NarrowWgradArgs a) {
     const ZT* const dzp = reinterpret_cast<const ZT*>(a.dz);
     constexpr int XWIN = 3 * SI + KT;
+    constexpr int NA = CIN * KT + 1;                       // accumulators per dz row: CIN x KT taps + the bias sum
+    static_assert(NPW * NA <= 128, "one accumulator per lane of two registers");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n0 = wave * NPW;
+    const int n0 = a.nrow0 + wave * NPW;                   // first dz row of this wave (nrow0: rows [nrow0, nrow0 + 24) per launch)
 
-    float acc[NPW][KT + 1];
+    float acc[NPW][NA];
 #pragma unroll
     for (int n = 0; n < NPW; ++n)
 #pragma unroll
-        for (int k = 0; k <= KT; ++k) acc[n][k] = 0.f;
+        for (int k = 0; k < NA; ++k) acc[n][k] = 0.f;
 
     // row bases of this wave's dz rows (wave-uniform): source s = n / Nper, channel c = n % Nper
     long long zrow[NPW];
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(64 * (24 / NPW)) void narrow_stream_kernel(NarrowWg
     const int u0 = blockIdx.x * a.units_per_split;
     int u1 = u0 + a.units_per_split;
     if (u1 > nunits) u1 = nunits;
-    auto load_unit = [&](int u, float (&xv)[XWIN], f32x4 (&z)[NPW]) __attribute__((always_inline)) {
+    auto load_unit = [&](int u, float (&xv)[CIN][XWIN], f32x4 (&z)[NPW]) __attribute__((always_inline)) {
         const int b = u / a.nQT, qt = u - b * a.nQT;
         const int q = qt * 256 + 4 * lane;                      // first of this lane's four positions
         const int t0 = q * SI - a.shift;                        // input sample under tap 0 of position q
@@ -198,19 +201,24 @@ __global__ __launch_bounds__(64 * (24 / NPW)) void narrow_stream_kernel(NarrowWg
         const int tq_lo = qt * 256 * SI - a.shift, tq_hi = (qt * 256 + 255) * SI - a.shift + KT - 1;
         const bool interior = tq_lo >= 0 && tq_hi < a.Tin && qt * 256 + 255 < a.Tq && qt * 256 + 255 < a.dzpitch;
         if (interior) {
-            const float* xp = xr + t0;
 #pragma unroll
-            for (int i = 0; i < XWIN; ++i) xv[i] = xp[i];
+            for (int ci = 0; ci < CIN; ++ci) {
+                const float* xp = xr + (long long)ci * a.pitch0 + t0;
+#pragma unroll
+                for (int i = 0; i < XWIN; ++i) xv[ci][i] = xp[i];
+            }
 #pragma unroll
             for (int n = 0; n < NPW; ++n) z[n] = ld4<ZT>(zb, zrow[n]);
         } else {
 #pragma unroll
-            for (int i = 0; i < XWIN; ++i) {
-                const int t = t0 + i;
-                const int tc = t < 0 ? 0 : (t > a.Tin - 1 ? a.Tin - 1 : t);
-                const float v = xr[tc];
-                xv[i] = (t >= 0 && t < a.Tin) ? v : 0.f;
-            }
+            for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                for (int i = 0; i < XWIN; ++i) {
+                    const int t = t0 + i;
+                    const int tc = t < 0 ? 0 : (t > a.Tin - 1 ? a.Tin - 1 : t);
+                    const float v = xr[(long long)ci * a.pitch0 + tc];
+                    xv[ci][i] = (t >= 0 && t < a.Tin) ? v : 0.f;
+                }
 #pragma unroll
             for (int n = 0; n < NPW; ++n) {
 #pragma unroll
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(64 * (24 / NPW)) void narrow_stream_kernel(NarrowWg
         }
     };
     // the loads of unit u + 1 are in flight while the FMAs of unit u run (two register sets)
-    float xa[XWIN], xb[XWIN];
+    float xa[CIN][XWIN], xb[CIN][XWIN];
     f32x4 za[NPW], zb2[NPW];
     if (PF && u0 < u1) load_unit(u0, xa, za);
     for (int u = u0; u < u1; ++u) {
@@ -233,27 +241,31 @@ __global__ __launch_bounds__(64 * (24 / NPW)) void narrow_stream_kernel(NarrowWg
 #pragma unroll
         for (int n = 0; n < NPW; ++n) {
 #pragma unroll
-            for (int k = 0; k < KT; ++k)
+            for (int ci = 0; ci < CIN; ++ci)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[n][k] = fmaf(xa[r * SI + k], za[n][r], acc[n][k]);
-            acc[n][KT] += (za[n][0] + za[n][1]) + (za[n][2] + za[n][3]);
+                for (int k = 0; k < KT; ++k)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[n][ci * KT + k] = fmaf(xa[ci][r * SI + k], za[n][r], acc[n][ci * KT + k]);
+            acc[n][CIN * KT] += (za[n][0] + za[n][1]) + (za[n][2] + za[n][3]);
         }
         if (more) {
 #pragma unroll
-            for (int i = 0; i < XWIN; ++i) xa[i] = xb[i];
+            for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                for (int i = 0; i < XWIN; ++i) xa[ci][i] = xb[ci][i];
 #pragma unroll
             for (int n = 0; n < NPW; ++n) za[n] = zb2[n];
         }
     }
     // ---- 64 lanes -> 1 per accumulator: rows of 16 lanes by DPP shifts (lane 15 of a row ends up with the row's sum),
     // then the four row totals in row order; total j is kept by lane j (two registers: 64 + the rest) ----
-    const int P = (a.KW + 1) * a.N;
+    const int P = (a.KW * CIN + 1) * a.N;
     float* out = a.partial + (long long)(a.split_base + blockIdx.x) * P;
     float keep0 = 0.f, keep1 = 0.f;
 #pragma unroll
     for (int n = 0; n < NPW; ++n)
 #pragma unroll
-        for (int k = 0; k <= KT; ++k) {
+        for (int k = 0; k < NA; ++k) {
             float v = acc[n][k];
             v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xF, 0xF, false));
             v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xF, 0xF, false));
@@ -264,21 +276,24 @@ __global__ __launch_bounds__(64 * (24 / NPW)) void narrow_stream_kernel(NarrowWg
                                 __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 31))) +
                                __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 47))) +
                               __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 63));
-            constexpr int dummy = 0; (void)dummy;
-            const int j = n * (KT + 1) + k;
+            const int j = n * NA + k;
             if (j < 64) keep0 = lane == j ? tot : keep0;
             else keep1 = lane == j - 64 ? tot : keep1;
         }
-    // lane j holds accumulator j = n * (KT + 1) + k of this wave: weights out[k * N + n0 + n] (k < KW), bias out[KW * N + n0 + n]
+    // lane j holds accumulator j = n * NA + (ci * KT + k) of this wave: weights out[(k * CIN + ci) * N + n0 + n] (k < KW),
+    // bias out[KW * CIN * N + n0 + n]
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int j = lane + 64 * h;
-        if (j < NPW * (KT + 1)) {
-            const int n = j / (KT + 1), k = j - n * (KT + 1);
+        if (j < NPW * NA) {
+            const int n = j / NA, kk = j - n * NA;
             const float v = h ? keep1 : keep0;
-            if (n0 + n < a.N) {
-                if (k < a.KW) out[k * a.N + n0 + n] = v;
-                else if (k == KT) out[a.KW * a.N + n0 + n] = v;
+            if (n0 + n < a.N && wave * NPW + n < 24) {
+                if (kk == CIN * KT) out[a.KW * CIN * a.N + n0 + n] = v;
+                else {
+                    const int ci = kk / KT, k = kk - ci * KT;
+                    if (k < a.KW) out[(k * CIN + ci) * a.N + n0 + n] = v;
+                }
             }
         }
     }
@@ -293,7 +308,8 @@ static bool narrow_stream_ok(const NarrowWgradArgs& a) {
     static const bool off = getenv("WUN_NO_NARROW_STREAM") != nullptr && atoi(getenv("WUN_NO_NARROW_STREAM")) != 0;
     // (the kernel reads src0 only, in 256-position units)
     static_assert(WUN_NW_TQ == 256, "narrow_stream_kernel walks units of 4 positions x 64 lanes");
-    return !off && a.C0 == 1 && a.C1 == 0 && a.N <= 24 && a.KW >= 4 && a.KW <= 15;
+    // one or two input channels (the reference's mono / stereo audio), up to 48 dz rows (two launches of 24)
+    return !off && (a.C0 == 1 || a.C0 == 2) && a.C1 == 0 && a.N <= 48 && a.KW >= 4 && a.KW <= 15;
 }
 
 // out element (k, ci, n = s*Nper + c) -> source s: weights [K][Ctot][Nper] at woff[s], bias at boff[s].
@@ -366,17 +382,23 @@ hipError_t launch_narrow_wgrad(NarrowWgradArgs a, hipStream_t s) {
     a.units_per_split = (units + a.nsplit - 1) / a.nsplit;
     if (narrow_stream_ok(a)) {
         char tag[160];
-        snprintf(tag, sizeof(tag), "C=1 N=%d T=%d K=%d stride=%d B=%d nsplit=%d stream", a.N, a.Tq, a.KW, a.stride, a.B, a.nsplit);
-        prof_scope_begin("narrow_wgrad_kernel", 2.0 * a.KW * (double)a.N * (double)a.Tq * a.B, s, tag,
-                         (double)a.B * a.Tq * (((a.et & 4) ? 2.0 : 4.0) * a.N + 4.0 * a.stride));
+        snprintf(tag, sizeof(tag), "C=%d N=%d T=%d K=%d stride=%d B=%d nsplit=%d stream", a.C0, a.N, a.Tq, a.KW, a.stride, a.B, a.nsplit);
+        prof_scope_begin("narrow_wgrad_kernel", 2.0 * a.KW * (double)a.C0 * a.N * (double)a.Tq * a.B, s, tag,
+                         (double)a.B * a.Tq * (((a.et & 4) ? 2.0 : 4.0) * a.N + 4.0 * a.C0 * a.stride));
         if (a.et & ~4) { prof_scope_end(s); return hipErrorInvalidValue; }      // (the audio itself is always fp32)
         const dim3 blk(64 * (24 / WUN_NS_NPW));
-        if (a.et & 4) {
-            if (a.stride == 2) hipLaunchKernelGGL((narrow_stream_kernel<15, 2, WUN_NS_NPW, WUN_NS_PF, bf16_t>), dim3((unsigned)a.nsplit), blk, 0, s, a);
-            else hipLaunchKernelGGL((narrow_stream_kernel<15, 1, WUN_NS_NPW, WUN_NS_PF, bf16_t>), dim3((unsigned)a.nsplit), blk, 0, s, a);
-        } else {
-            if (a.stride == 2) hipLaunchKernelGGL((narrow_stream_kernel<15, 2, WUN_NS_NPW, WUN_NS_PF, float>), dim3((unsigned)a.nsplit), blk, 0, s, a);
-            else hipLaunchKernelGGL((narrow_stream_kernel<15, 1, WUN_NS_NPW, WUN_NS_PF, float>), dim3((unsigned)a.nsplit), blk, 0, s, a);
+        // 24 dz rows per launch (the second launch of a 48-row layer writes the other rows of the same partial vectors)
+        for (int r0 = 0; r0 < a.N; r0 += 24) {
+            a.nrow0 = r0;
+#define WUN_NSK(SI, ZT, CI) hipLaunchKernelGGL((narrow_stream_kernel<15, SI, WUN_NS_NPW, WUN_NS_PF, ZT, CI>), dim3((unsigned)a.nsplit), blk, 0, s, a)
+            if (a.C0 == 1) {
+                if (a.et & 4) { if (a.stride == 2) WUN_NSK(2, bf16_t, 1); else WUN_NSK(1, bf16_t, 1); }
+                else { if (a.stride == 2) WUN_NSK(2, float, 1); else WUN_NSK(1, float, 1); }
+            } else {
+                if (a.et & 4) { if (a.stride == 2) WUN_NSK(2, bf16_t, 2); else WUN_NSK(1, bf16_t, 2); }
+                else { if (a.stride == 2) WUN_NSK(2, float, 2); else WUN_NSK(1, float, 2); }
+            }
+#undef WUN_NSK
         }
         prof_scope_end(s);
         return hipGetLastError();
