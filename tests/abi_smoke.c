@@ -34,7 +34,25 @@ int main(void) {
     CHECK(strcmp(ti.name, "separator/conv1d/kernel") == 0 && ti.ndim == 3 && ti.shape[0] == 15 && ti.shape[1] == 1 &&
           ti.shape[2] == 24 && ti.offset == 0, "first variable = separator/conv1d/kernel [15,1,24]");
     CHECK(wun_plan_tensor(plan, info.num_tensors, &ti) == WUN_ERR_INVALID, "tensor index past the table is refused");
+    /* where the activations live (wun_plan_activation): level 0 of M1 + context convolves 147443 samples to 147429, the
+     * decimated stream keeps the 73715 even positions, the skip window is the 16393-sample centre crop the last up level takes */
+    wun_activation_info ai;
+    CHECK(wun_plan_activation(plan, 0, 0, &ai) == WUN_OK && ai.channels == 24 && ai.frames == 73715 && ai.t0 == 0 &&
+          ai.tstep == 2 && ai.elem_bytes == 4 && ai.pitch >= ai.frames && ai.batch_stride == ai.channels * ai.pitch, "dec_0 geometry");
+    CHECK(wun_plan_activation(plan, 1, 0, &ai) == WUN_OK && ai.channels == 24 && ai.frames == 16393 && ai.tstep == 1 &&
+          ai.t0 == (147429 - 16393) / 2, "skip_0 = centre crop of the level-0 conv output (Utils.py:120-121)");
+    CHECK(wun_plan_activation(plan, 2, 0, &ai) == WUN_OK && ai.channels == 312, "bottleneck: 312 channels");
+    CHECK(wun_plan_activation(plan, 3, 11, &ai) == WUN_OK && ai.channels == 24 && ai.frames == 16389, "up conv 11 = the feature map");
+    CHECK(wun_plan_activation(plan, 3, 12, &ai) == WUN_ERR_INVALID && wun_plan_activation(plan, 7, 0, &ai) == WUN_ERR_INVALID,
+          "unknown activation kind / index is refused");
     wun_plan_destroy(plan);
+    /* the bf16 mode keeps its activations in HBM as bfloat16 (compute_dtype = 1, layer widths in groups of 8) */
+    cfg.compute_dtype = 1;
+    plan = NULL;
+    CHECK(wun_plan_create(&cfg, 16, tin, &plan) == WUN_OK && plan != NULL, "wun_plan_create (bf16 mode)");
+    CHECK(wun_plan_activation(plan, 0, 0, &ai) == WUN_OK && ai.elem_bytes == 2 && (ai.pitch & 7) == 0, "bf16 mode: dec_0 holds bfloat16, rows of 16 bytes");
+    wun_plan_destroy(plan);
+    cfg.compute_dtype = 0;
 
     /* error convention: negative status + message, never an abort (reference: assert, UnetAudioSeparator.py:55) */
     cfg.filter_size = 31;                                   /* > 15 taps: WUN_ERR_UNSUPPORTED (include/wun.h) */
