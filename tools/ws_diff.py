@@ -74,8 +74,14 @@ def main():
             continue
         seen.add((name, ix))
         off, Bn, C, T, pitch = int(kv["off"]), int(kv["B"]), int(kv["C"]), int(kv["T"]), int(kv["pitch"])
-        a0 = ws0[off:off + Bn * C * pitch].reshape(Bn, C, pitch)[:, :, :T]
-        a1 = ws1[off:off + Bn * C * pitch].reshape(Bn, C, pitch)[:, :, :T]
+        if int(kv.get("eb", 4)) == 2:                  # bf16 mode: the tensor holds bfloat16 elements (off is still in floats)
+            def as_f32(ws):
+                u16 = ws[off:off + (Bn * C * pitch + 1) // 2].view(np.uint16)[:Bn * C * pitch]
+                return (u16.astype(np.uint32) << 16).view(np.float32).reshape(Bn, C, pitch)[:, :, :T]
+            a0, a1 = as_f32(ws0), as_f32(ws1)
+        else:
+            a0 = ws0[off:off + Bn * C * pitch].reshape(Bn, C, pitch)[:, :, :T]
+            a1 = ws1[off:off + Bn * C * pitch].reshape(Bn, C, pitch)[:, :, :T]
         d = np.abs(a1 - a0)
         sc = max(np.abs(a0).max(), 1e-30)
         rel = d.max() / sc
