@@ -129,6 +129,17 @@ int wun_plan_tensor(const wun_plan* plan, int64_t index, wun_tensor_info* info);
  *                                                         same padding: the whole conv output)
  *   kind 2          : bottleneck conv output (:102)
  *   kind 3, index j : output of up conv j (:123)
+ * and, for the layer-by-layer parity tests of the bf16 mode (each launch's output against a float64 computation from the
+ * tensors that launch read; tests/test_gpu_bf16.py), the other tensors a training step leaves in the workspace -- valid
+ * after wun_loss_backward, same addressing, no activation implied:
+ *   kind 4, index j : the 2x-upsampled input of up conv j (:109-118); not written by plans whose split-K epilogue
+ *                     fuses the interpolation (compute_dtype = 0)
+ *   kind 5, index j : d loss / d pre-activation of up conv j
+ *   kind 6, index j : d loss / d (tensor of kind 4); compute_dtype = 0: only where the adjoint is not fused
+ *   kind 7, index i : d loss / d pre-activation of down conv i at the positions of kind 1
+ *   kind 8, index i : d loss / d pre-activation of down conv i at the positions of kind 0 (context only; with same
+ *                     padding kind 7 holds the whole row)
+ *   kind 9          : d loss / d pre-activation of the bottleneck conv
  * All fields are int64.  WUN_ERR_INVALID for an unknown kind / index. */
 typedef struct wun_activation_info {
     int64_t offset;                         /* of the tensor, in FLOATS from the workspace base */

@@ -43,8 +43,17 @@ int main(void) {
           ai.t0 == (147429 - 16393) / 2, "skip_0 = centre crop of the level-0 conv output (Utils.py:120-121)");
     CHECK(wun_plan_activation(plan, 2, 0, &ai) == WUN_OK && ai.channels == 312, "bottleneck: 312 channels");
     CHECK(wun_plan_activation(plan, 3, 11, &ai) == WUN_OK && ai.channels == 24 && ai.frames == 16389, "up conv 11 = the feature map");
-    CHECK(wun_plan_activation(plan, 3, 12, &ai) == WUN_ERR_INVALID && wun_plan_activation(plan, 7, 0, &ai) == WUN_ERR_INVALID,
-          "unknown activation kind / index is refused");
+    /* ... and the gradient tensors of a training step (kinds 4 - 9): d loss / d pre-activation lives where the activation's
+     * positions are -- the skip window's gradient has the skip window's geometry, the decimated stream's likewise */
+    CHECK(wun_plan_activation(plan, 7, 0, &ai) == WUN_OK && ai.channels == 24 && ai.frames == 16393 && ai.t0 == (147429 - 16393) / 2,
+          "dz_skip_0 has the geometry of skip_0");
+    CHECK(wun_plan_activation(plan, 8, 0, &ai) == WUN_OK && ai.frames == 73715 && ai.tstep == 2, "dz_dec_0 has the geometry of dec_0");
+    CHECK(wun_plan_activation(plan, 4, 11, &ai) == WUN_OK && ai.channels == 48 && ai.frames == 16393, "upsampled input of up conv 11: 48 x 16393");
+    CHECK(wun_plan_activation(plan, 5, 11, &ai) == WUN_OK && ai.channels == 24 && ai.frames == 16389 &&
+          wun_plan_activation(plan, 6, 11, &ai) == WUN_OK && ai.channels == 48 && ai.frames == 16393 &&
+          wun_plan_activation(plan, 9, 0, &ai) == WUN_OK && ai.channels == 312, "dz_up_11, d_ups_11, dz_bottleneck");
+    CHECK(wun_plan_activation(plan, 3, 12, &ai) == WUN_ERR_INVALID && wun_plan_activation(plan, 10, 0, &ai) == WUN_ERR_INVALID &&
+          wun_plan_activation(plan, 9, 1, &ai) == WUN_ERR_INVALID, "unknown activation kind / index is refused");
     wun_plan_destroy(plan);
     /* the bf16 mode keeps its activations in HBM as bfloat16 (compute_dtype = 1, layer widths in groups of 8) */
     cfg.compute_dtype = 1;

@@ -19,7 +19,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from oracle import shapes, waveunet_torch as wt
+from oracle import bf16_emul, shapes, waveunet_torch as wt
 from oracle.golden_params import GOLDEN_CASES, golden_params
 from _observed import record
 
@@ -38,6 +38,18 @@ BF16_INTERP_L2_TOL = 6e-1     # bias / interp vectors, relative L2; observed <= 
 BF16_INTERP_MAX_TOL = 7.5e-1    # x max|g| for the learned-interpolation vectors alone: each element is the difference of two long
                               # sums of bf16-rounded products over a handful of positions (interp_0 of M5 at full size: 312
                               # elements from a 9-position bottleneck row at B = 2; observed 0.33 with fp32 activations in HBM, 0.50 with bf16 ones)
+# vs oracle/bf16_emul.py in its layer-by-layer mode -- every tensor the step leaves in the workspace against a float64
+# computation (with the plan's bf16 storage roundings) from the tensors the producing launch READ, every weight gradient
+# against float64 sums over the stored operands: what is left is fp32 accumulation order and the rare element whose fp32
+# sum lands on the other side of a bf16 rounding boundary (one bf16 ulp = 2^-8 .. 2^-7 of the value).  (Chained, those
+# flips feed on themselves -- oracle/bf16_emul.py:train_step -- and after a few layers two valid executions differ by
+# the rounding noise of the mode: that is the comparison with the un-rounded oracle above.)
+EMUL_FLIP_TOL = 5e-3          # fraction of a stored tensor's elements that differ from the emulation's at all
+EMUL_MAX_ULPS = 4.1           # ... and by how much at most, in units of 2^-8 |value| (one ulp is 1 .. 2 of these; a tensor
+                              # stored twice -- a down level's input gradient inside the skip window -- can be off by two)
+EMUL_KERNEL_GRAD_L2_TOL = 2e-4   # conv kernels' gradients, ||g - g_emul||_2 / ||g_emul||_2
+EMUL_VECTOR_GRAD_L2_TOL = 5e-3   # bias / learned-interpolation vectors (long fp32 sums with cancellation)
+EMUL_LOSS_TOL = 1e-5
 BF16_GRAD_L2_TOL = 1.1e-1  # per gradient tensor ||g - g_ref||_2 / ||g_ref||_2: the sharper norm for rounding noise (a wrong tap
                          # or a dropped channel group of a narrow layer moves it by O(1/sqrt(taps)) ~ 0.3+); observed <= 3.6e-2 on conv kernels (3x)
 
@@ -263,7 +275,59 @@ def _step(cfg_over, ocfg, params, B, frames, seed, tag, tune=False):
     assert worst_interp_max <= BF16_INTERP_MAX_TOL, worst_interp_max
     assert worst_l2[0] <= BF16_GRAD_L2_TOL, worst_l2
     assert worst_interp <= BF16_INTERP_L2_TOL, worst_interp
+    if sep.activation("bottleneck")[0].dtype == torch.bfloat16:     # (plans that fell back to exact fp32 have nothing to emulate)
+        _compare_with_emulation(sep, ocfg, params, mix, targets, loss.item(), g, tag)
     return sep
+
+
+def _compare_with_emulation(sep, ocfg, params, mix, targets, gpu_loss, g, tag):
+    """The same step, layer by layer, against oracle/bf16_emul.py: every stored tensor (wun_plan_activation kinds 0 - 9)
+    is handed to the emulation as the input of whatever reads it, and compared with what the emulation computes for it
+    from ITS producer's (given) inputs; the loss and every gradient tensor likewise."""
+    L, same = ocfg["num_layers"], not ocfg["context"]
+    forced = {}
+
+    def take(name, kind, idx=0):
+        forced[name] = sep.activation(kind, idx)[0].cpu().double()
+
+    for i in range(L):
+        take("dec%d" % i, "dec", i); take("skip%d" % i, "skip", i); take("dz_skip%d" % i, "dz_skip", i)
+        if not same:
+            take("dz_dec%d" % i, "dz_dec", i)
+        take("ups%d" % i, "ups", i); take("up%d" % i, "up", i); take("dz_up%d" % i, "dz_up", i); take("d_ups%d" % i, "d_ups", i)
+    take("bottleneck", "bottleneck"); take("dz_bottleneck", "dz_bottleneck")
+    eloss, egrads, inter = bf16_emul.train_step(ocfg, params, mix, targets, forced=forced)
+    assert set(forced) == set(inter) - {"outputs"}, sorted(set(forced) ^ (set(inter) - {"outputs"}))
+    worst_flip, worst_ulps = (0.0, ""), (0.0, "")
+    for name, got in forced.items():
+        ref = inter[name]
+        diff = (got - ref).abs()
+        rms = ref.pow(2).mean().sqrt().item()
+        unit = torch.clamp(ref.abs(), min=1e-2 * rms + 1e-30) * 2.0 ** -8     # (near-zero elements: fp32 noise, not flips)
+        frac = (diff > 0).double().mean().item()
+        mx = (diff / unit).max().item()
+        if frac > worst_flip[0]:
+            worst_flip = (frac, name)
+        if mx > worst_ulps[0]:
+            worst_ulps = (mx, name)
+    record("bf16_stored_tensors_differing_fraction_vs_layerwise_emulation", "%s (worst: %s)" % (tag, worst_flip[1]), worst_flip[0], EMUL_FLIP_TOL)
+    record("bf16_stored_tensors_max_ulps_vs_layerwise_emulation", "%s (worst: %s)" % (tag, worst_ulps[1]), worst_ulps[0], EMUL_MAX_ULPS)
+    el = abs(gpu_loss - eloss) / max(abs(eloss), 1e-3)
+    record("bf16_loss_vs_layerwise_emulation", tag, el, EMUL_LOSS_TOL)
+    wk, wv = (0.0, ""), (0.0, "")
+    for (n, _), eg in zip(params, egrads):
+        got = g[n].cpu().double()
+        l2 = (got - eg).norm().item() / max(eg.norm().item(), 1e-30)
+        if n.endswith("/kernel"):
+            if l2 > wk[0]:
+                wk = (l2, n)
+        elif l2 > wv[0]:
+            wv = (l2, n)
+    record("bf16_kernel_gradients_rel_l2_vs_layerwise_emulation", "%s (worst: %s)" % (tag, wk[1]), wk[0], EMUL_KERNEL_GRAD_L2_TOL)
+    record("bf16_vector_gradients_rel_l2_vs_layerwise_emulation", "%s (worst: %s)" % (tag, wv[1]), wv[0], EMUL_VECTOR_GRAD_L2_TOL)
+    assert worst_flip[0] <= EMUL_FLIP_TOL and worst_ulps[0] <= EMUL_MAX_ULPS, (worst_flip, worst_ulps)
+    assert el <= EMUL_LOSS_TOL, el
+    assert wk[0] <= EMUL_KERNEL_GRAD_L2_TOL and wv[0] <= EMUL_VECTOR_GRAD_L2_TOL, (wk, wv)
 
 
 @pytest.mark.parametrize("name", ["baseline_small", "baseline_stereo_small", "full_small", "full_multi_small",

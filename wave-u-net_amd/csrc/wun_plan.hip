@@ -526,6 +526,12 @@ extern "C" int wun_plan_activation(const wun_plan* p, int32_t kind, int32_t inde
     else if (kind == 1 && index >= 0 && index < p->L) { b = &p->skip[(size_t)index]; t0 = p->same ? 0 : p->dsh[(size_t)index].cs; }
     else if (kind == 2 && index == 0) b = &p->bott_out;
     else if (kind == 3 && index >= 0 && index < p->L) b = &p->upo[(size_t)index];
+    else if (kind == 4 && index >= 0 && index < p->L) b = &p->ups[(size_t)index];
+    else if (kind == 5 && index >= 0 && index < p->L) b = &p->dz_upo[(size_t)index];
+    else if (kind == 6 && index >= 0 && index < p->L) b = &p->d_ups[(size_t)index];
+    else if (kind == 7 && index >= 0 && index < p->L) { b = &p->dz_skip[(size_t)index]; t0 = p->same ? 0 : p->dsh[(size_t)index].cs; }
+    else if (kind == 8 && index >= 0 && index < p->L && !p->same) { b = &p->dz_dec[(size_t)index]; tstep = 2; }
+    else if (kind == 9 && index == 0) b = &p->dz_bott;
     if (b == nullptr) return fail(WUN_ERR_INVALID, "wun_plan_activation: unknown kind / index");
     info->offset = b->off; info->batch_stride = b->bs; info->pitch = b->pitch;
     info->channels = b->C; info->frames = b->T; info->t0 = t0; info->tstep = tstep; info->elem_bytes = b->eb;

@@ -289,10 +289,13 @@ class UnetAudioSeparator(object):
     def activation(self, kind, index=0):
         """(tensor view [B, C, frames], t0, tstep) of a forward activation kept in the workspace of the last
         get_output(training=True): kind "dec" / "skip" (down level `index`), "bottleneck", "up" (up conv `index`);
-        element j of a row is the post-activation conv output at position t0 + j * tstep (wun_plan_activation)."""
+        element j of a row is the post-activation conv output at position t0 + j * tstep (wun_plan_activation).
+        After loss_and_gradients also "ups" (upsampled input of up conv `index`), "dz_up", "d_ups", "dz_skip", "dz_dec",
+        "dz_bottleneck": the gradient tensors the backward pass left in the workspace (wun.h, kinds 4 - 9)."""
         info = _lib.WunActivationInfo()
-        _lib.check(self._lib.wun_plan_activation(self._active.handle, {"dec": 0, "skip": 1, "bottleneck": 2, "up": 3}[kind],
-                                                 int(index), C.byref(info)))
+        kinds = {"dec": 0, "skip": 1, "bottleneck": 2, "up": 3, "ups": 4, "dz_up": 5, "d_ups": 6, "dz_skip": 7, "dz_dec": 8,
+                 "dz_bottleneck": 9}
+        _lib.check(self._lib.wun_plan_activation(self._active.handle, kinds[kind], int(index), C.byref(info)))
         B = int(self._active.info.batch)
         ws = self._ws[self._last_key]
         if info.elem_bytes == 2:                                   # bf16 mode: activations live in HBM as bfloat16
