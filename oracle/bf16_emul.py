@@ -176,8 +176,14 @@ def train_step(cfg, params, mix_btc, targets, quantize=True, forced=None):
     x_in = torch.as_tensor(np.asarray(mix_btc), dtype=torch.float64).permute(0, 2, 1).contiguous()
     inter = {}
 
-    def store(name, value):
+    inter["_scale"] = {}
+
+    def store(name, value, scale=None):
+        # scale: magnitude of the operands of a store that ADDS onto an earlier store (the earlier one may itself have landed
+        # on either side of a rounding boundary: the sum is then off by an ulp of the OPERAND, many ulps of a cancelling sum)
         inter[name] = value
+        if scale is not None:
+            inter["_scale"][name] = scale
         if forced is not None and name in forced:
             f = torch.as_tensor(forced[name]).to(torch.float64)
             assert f.shape == value.shape, (name, tuple(f.shape), tuple(value.shape))
@@ -287,8 +293,10 @@ def train_step(cfg, params, mix_btc, targets, quantize=True, forced=None):
             ik, ib, xi, w = tape[i]
             acc = dz_skip[i].clone()
             m = _mask(skcs[i][1])[:, :, ::2]
+            mag = acc.abs()
+            mag[:, :, ::2] = torch.maximum(mag[:, :, ::2], (m * dcur).abs())
             acc[:, :, ::2] = q.a(m * dcur + acc[:, :, ::2])
-            dzs = store("dz_skip%d" % i, acc)
+            dzs = store("dz_skip%d" % i, acc, mag)
             dcur, G[ik], G[ib] = _conv_adjoint(xi, w, dzs, True, need_dx=(i > 0))
         assert all(g is not None for g in G)
         return loss, G, inter
@@ -305,7 +313,10 @@ def train_step(cfg, params, mix_btc, targets, quantize=True, forced=None):
         if i > 0:
             m = _mask(decs[i - 1])
             st = q.a(m * g1)                                        # launch 1: fused two-phase transposed conv, stored
-            st[:, :, s0:s0 + tc + K - 1] = q.a(m[:, :, s0:s0 + tc + K - 1] * g2 + st[:, :, s0:s0 + tc + K - 1])   # launch 2: F_ACCUM
-            dzd = store("dz_dec%d" % (i - 1), st)
+            mag = st.abs()
+            win = slice(s0, s0 + tc + K - 1)
+            mag[:, :, win] = torch.maximum(mag[:, :, win], (m[:, :, win] * g2).abs())
+            st[:, :, win] = q.a(m[:, :, win] * g2 + st[:, :, win])  # launch 2: F_ACCUM inside the skip window
+            dzd = store("dz_dec%d" % (i - 1), st, mag)
     assert all(g is not None for g in G)
     return loss, G, inter

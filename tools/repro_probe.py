@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Is a training step bit-reproducible across fresh separators of one process?  (GPU box.)
+
+Runs a handful of small configurations first (process history: earlier plans, their streams, recycled allocations), then
+the M4 configuration (BASELINE.json configs[2]: context + stereo + difference output, 147443 -> 16389 samples, B = 2) nine
+times on fresh separators and compares loss, outputs, every gradient tensor and every tensor the step leaves in the
+workspace (wun_plan_activation kinds 0 - 9) BITWISE with the first run.  This is the probe that found the bf16 mode's
+head weight gradient differing from run to run when wgrad_bf16_kernel ran beside narrow_wgrad_kernel;
+WUN_BF16_HEAD_OVERLAP=1 restores that launch order.
+usage: python tools/repro_probe.py [bf16|f32]      (DIAG_SAME=1: the same-padding variant of the configuration)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import wave_u_net_amd as wun
+from wave_u_net_amd.separator import UnetAudioSeparator
+from oracle import shapes, waveunet_torch as wt
+from oracle.golden_params import GOLDEN_CASES, golden_params
+
+KINDS = ["dec", "skip", "dz_skip", "dz_dec", "ups", "up", "dz_up", "d_ups"]
+
+def step(over, seed_p, B, frames, seed_d, dtype="bf16", collect=True):
+    ocfg = shapes.finalize_config(dict(shapes.BASE_MODEL_CONFIG, **over))
+    params = golden_params(ocfg, seed_p)
+    sep = UnetAudioSeparator(wun.get_config("baseline", compute_dtype=dtype, **over), device="cuda:0")
+    i, o = shapes.get_padding(ocfg, [B, frames, 0])
+    mix, targets = wt.synthetic_batch(ocfg, B, i[1], o[1], seed=seed_d)
+    sep._plan(B, i[1]); sep._active = sep._plans[(B, i[1])]
+    sep.load_variables(params)
+    outs = sep.get_output(torch.from_numpy(mix).cuda(), True)
+    loss = sep.loss_and_gradients({k: torch.from_numpy(v) for k, v in targets.items()})
+    torch.cuda.synchronize()
+    res = {"loss": loss.detach().cpu().clone()}
+    for n, t in sep.gradients().items(): res["g:" + n] = t.detach().cpu().clone()
+    for n, t in outs.items(): res["o:" + n] = t.detach().cpu().clone()
+    if collect:
+        L = ocfg["num_layers"]
+        for k in range(L):
+            for kind in KINDS:
+                if kind == "dz_dec" and not ocfg["context"]: continue
+                res["%s%d" % (kind, k)] = sep.activation(kind, k)[0].cpu().clone()
+        res["bottleneck"] = sep.activation("bottleneck")[0].cpu().clone()
+        res["dz_bottleneck"] = sep.activation("dz_bottleneck")[0].cpu().clone()
+    return res
+
+over = dict(output_type="difference", context=(os.environ.get("DIAG_SAME") is None), mono_downmix=False)
+for name in ["baseline_small", "baseline_stereo_small", "full_small", "full_multi_small", "learned_same_small"]:
+    case = GOLDEN_CASES[name]
+    step(case["cfg"], case["seed"], 3, case["frames"], case["seed"] + 100, collect=False)
+dt = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+ref = step(over, 91, 2, 16384, 92, dt)
+for r in range(8):
+    got = step(over, 91, 2, 16384, 92, dt)
+    diffs = []
+    for k in ref:
+        if not torch.equal(got[k], ref[k]):
+            a, b = got[k].double().flatten(), ref[k].double().flatten()
+            nz = (a != b).nonzero().flatten()
+            diffs.append("%s: %d of %d differ (first idx %d..%d), max rel %.2e" % (k, nz.numel(), a.numel(), int(nz[0]), int(nz[-1]),
+                         float((a - b).abs().max() / max(b.abs().max().item(), 1e-30))))
+    print("[%s] repeat %d: %s" % (dt, r, "bitwise identical" if not diffs else " | ".join(diffs)), flush=True)

@@ -1355,7 +1355,18 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
         if (narrow_wgrad_supported(nw) && (p->bf16 || getenv("WUN_NO_NARROW") == nullptr)) {
             long long woff[4] = {0, 0, 0, 0}, boff[4] = {0, 0, 0, 0};
             for (int sh = 0; sh < p->Sh; ++sh) { woff[sh] = p->head[sh].woff; boff[sh] = p->head[sh].boff; }
-            if ((rc = run_narrow_wgrad(p, &nw, 1, woff, boff, ws, grads, s, wstream()))) return rc;
+            hipStream_t hs = wstream();
+            if ((rc = run_narrow_wgrad(p, &nw, 1, woff, boff, ws, grads, s, hs))) return rc;
+            // bf16 mode: the OTHER side stream starts after this launch.  Measured (round 5, tools/repro_probe.py):
+            // with ragged rows (context: 16389 output positions) the head's kernel gradient came out different by 1e-5 .. 3e-4
+            // of max|g| in 10 - 100 % of the steps of a process -- whole 64-byte lines of narrow_wgrad_kernel's split partials
+            // read back wrong by its reduction -- if and only if the up level's wgrad_bf16_kernel (other side stream) ran beside
+            // it; every other tensor of the step stayed bit-identical, the exact-fp32 mode and same-padding shapes never showed
+            // it, nor did this order (3 x 8 steps) or the launch on the caller's stream (2 x 8).  Root cause not found (no buffer
+            // of the two launches overlaps, LDS contents and staged inputs verified inside the kernel); the order costs the
+            // dependent chain nothing (no packet on `stream`) and the side stream one ~30 us launch
+            if (p->bf16 && s3 != s2 && hs != s && getenv("WUN_BF16_HEAD_OVERLAP") == nullptr &&
+                (rc = stream_dep(p, hs, hs == s2 ? s3 : s2))) return rc;
             head_done = true;
         } else if (p->bf16) {
             // bf16 mode: the head's inputs are the fp32 audio and the bf16 feature map -- only the narrow kernels read
