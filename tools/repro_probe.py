@@ -7,7 +7,7 @@ times on fresh separators and compares loss, outputs, every gradient tensor and 
 workspace (wun_plan_activation kinds 0 - 9) BITWISE with the first run.  This is the probe that found the bf16 mode's
 head weight gradient differing from run to run when wgrad_bf16_kernel ran beside narrow_wgrad_kernel (DESIGN.md 5g);
 WUN_BF16_HEAD_OVERLAP=1 restores that launch order.
-usage: python tools/repro_probe.py [bf16|f32]      (DIAG_SAME=1: the same-padding variant of the configuration)"""
+usage: python tools/repro_probe.py [bf16|f32] [m4|m4_same|m1_context|m5|multi|multi_direct]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -42,12 +42,22 @@ def step(over, seed_p, B, frames, seed_d, dtype="bf16", collect=True):
         res["dz_bottleneck"] = sep.activation("dz_bottleneck")[0].cpu().clone()
     return res
 
-over = dict(output_type="difference", context=(os.environ.get("DIAG_SAME") is None), mono_downmix=False)
+CONFIGS = {
+    "m4": dict(output_type="difference", context=True, mono_downmix=False),                       # BASELINE.json configs[2]
+    "m4_same": dict(output_type="difference", context=False, mono_downmix=False),
+    "m1_context": dict(context=True),                                                             # the headline shape (mono)
+    "m5": dict(output_type="difference", context=True, mono_downmix=False, upsampling="learned"),
+    "multi": dict(output_type="difference", context=True, mono_downmix=False, task="multi_instrument"),
+    "multi_direct": dict(context=True, mono_downmix=False, task="multi_instrument"),
+}
+dt = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+which = sys.argv[2] if len(sys.argv) > 2 else "m4"
+over = CONFIGS[which]
 for name in ["baseline_small", "baseline_stereo_small", "full_small", "full_multi_small", "learned_same_small"]:
     case = GOLDEN_CASES[name]
     step(case["cfg"], case["seed"], 3, case["frames"], case["seed"] + 100, collect=False)
-dt = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 ref = step(over, 91, 2, 16384, 92, dt)
+nbad = 0
 for r in range(8):
     got = step(over, 91, 2, 16384, 92, dt)
     diffs = []
@@ -57,4 +67,6 @@ for r in range(8):
             nz = (a != b).nonzero().flatten()
             diffs.append("%s: %d of %d differ (first idx %d..%d), max rel %.2e" % (k, nz.numel(), a.numel(), int(nz[0]), int(nz[-1]),
                          float((a - b).abs().max() / max(b.abs().max().item(), 1e-30))))
-    print("[%s] repeat %d: %s" % (dt, r, "bitwise identical" if not diffs else " | ".join(diffs)), flush=True)
+    nbad += bool(diffs)
+    print("[%s %s] repeat %d: %s" % (which, dt, r, "bitwise identical" if not diffs else " | ".join(diffs)), flush=True)
+print("[%s %s] %d of 8 repeats differ from the first run" % (which, dt, nbad))
