@@ -58,7 +58,8 @@ for name in ["baseline_small", "baseline_stereo_small", "full_small", "full_mult
     step(case["cfg"], case["seed"], 3, case["frames"], case["seed"] + 100, collect=False)
 ref = step(over, 91, 2, 16384, 92, dt)
 nbad = 0
-for r in range(8):
+NREP = int(os.environ.get('REPRO_REPEATS', '8'))
+for r in range(NREP):
     got = step(over, 91, 2, 16384, 92, dt)
     diffs = []
     for k in ref:
@@ -68,5 +69,7 @@ for r in range(8):
             diffs.append("%s: %d of %d differ (first idx %d..%d), max rel %.2e" % (k, nz.numel(), a.numel(), int(nz[0]), int(nz[-1]),
                          float((a - b).abs().max() / max(b.abs().max().item(), 1e-30))))
     nbad += bool(diffs)
+    if len(diffs) > 6:
+        diffs = diffs[:6] + ["... %d tensors in all" % len(diffs)]
     print("[%s %s] repeat %d: %s" % (which, dt, r, "bitwise identical" if not diffs else " | ".join(diffs)), flush=True)
-print("[%s %s] %d of 8 repeats differ from the first run" % (which, dt, nbad))
+print("[%s %s] %d of %d repeats differ from the first run" % (which, dt, nbad, NREP))

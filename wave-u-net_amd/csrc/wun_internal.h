@@ -267,6 +267,7 @@ void prof_scope_end(hipStream_t s);
 
 // ---- narrow weight gradients (wun_narrow.hip) ----
 bool narrow_wgrad_supported(const NarrowWgradArgs& a);
+bool narrow_wgrad_uses_lds(const NarrowWgradArgs& a);      // the LDS-staged kernel (else the streaming form)
 int narrow_wgrad_units(const NarrowWgradArgs& a);
 int narrow_wgrad_pick_nsplit(const NarrowWgradArgs& a);
 long long narrow_wgrad_partial_floats(const NarrowWgradArgs& a);

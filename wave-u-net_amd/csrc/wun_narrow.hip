@@ -338,6 +338,9 @@ __global__ __launch_bounds__(256) void narrow_wgrad_reduce_kernel(const float* p
     else grads[boff[src] + c] = red[0];
 }
 
+// (the plan keeps the LDS-staged form off the CUs the bf16 weight gradient is using: wun_plan.hip, run_narrow_wgrad)
+bool narrow_wgrad_uses_lds(const NarrowWgradArgs& a) { return !narrow_stream_ok(a); }
+
 bool narrow_wgrad_supported(const NarrowWgradArgs& a) {
     const int Ctot = a.C0 + a.C1;
     if (Ctot * a.N > 256 || Ctot * a.N < 1) return false;

@@ -1170,8 +1170,29 @@ static int run_wgrad(const wun_plan* p, WgradArgs* parts, int nparts, const Conv
 // (a down level's decimated + window positions) write consecutive splits of one partial list; one reduction.
 static int run_narrow_wgrad(const wun_plan* p, NarrowWgradArgs* parts, int nparts, const long long* woff,
                             const long long* boff, float* ws, float* grads, hipStream_t main, hipStream_t s) {
-    int rcd = stream_dep(p, main, s);
-    if (rcd) return rcd;
+    int rcd = WUN_OK;
+    hipStream_t side_of_caller = s;                            // (bucket events of the data-parallel path are recorded there)
+    // bf16 mode: narrow_wgrad_kernel (the LDS-staged form: the output head, audio-input convs with < 4 taps) runs ALONE on the
+    // device -- on the caller's stream, after whatever the side streams still hold.  Measured (round 5, tools/repro_probe.py,
+    // DESIGN 5g(9)): with ragged rows (context: 16389 output positions) the head's kernel gradient came out different by
+    // 1e-5 .. 8e-4 of max|g| in 10 - 100 % of the steps of a process -- runs of 16 elements, once exactly the contribution of
+    // the last position of 8 channels -- whenever the up level's wgrad_bf16_kernel (other side stream) ran beside it, and once
+    // in 24 steps with only that stream held back (the dependent chain's conv_bf16_kernel still beside it); every other tensor
+    // of the step stayed bit-identical, the exact-fp32 mode and same-padding shapes never showed it, nor did the launch on
+    // the caller's stream.  Root cause not found (no buffer of the launches overlaps; LDS tiles, staged inputs and reduction
+    // slots verified by canaries inside the kernel).  The head is the first launch of the backward pass that leaves the
+    // caller's stream, so this costs the dependent chain the kernel itself (~30 us per step) and two idle joins.
+    // WUN_BF16_HEAD_OVERLAP=1: the old placement on a side stream.
+    if (p->bf16 && s != main && getenv("WUN_BF16_HEAD_OVERLAP") == nullptr) {
+        bool lds_form = false;
+        for (int i = 0; i < nparts; ++i) lds_form = lds_form || narrow_wgrad_uses_lds(parts[i]);
+        if (lds_form) {
+            if (p->side != nullptr && (rcd = stream_dep(p, p->side, main))) return rcd;
+            if (p->side2 != nullptr && (rcd = stream_dep(p, p->side2, main))) return rcd;
+            s = main;
+        }
+    }
+    if (s != main && (rcd = stream_dep(p, main, s))) return rcd;      // everything this launch reads has been issued on `main`
     const long long pcap = p->partial_floats / 2;
     float* partial = ws + p->partial_off + ((p->side2 && s == p->side2) ? pcap : 0);
     int total = 0;
@@ -1188,6 +1209,8 @@ static int run_narrow_wgrad(const wun_plan* p, NarrowWgradArgs* parts, int npart
         done += parts[i].nsplit;
     }
     HIP_TRY(launch_narrow_wgrad_reduce(parts[0], partial, total, grads, woff, boff, s));
+    // (moved to `main`: the side stream the caller named is where it records "gradients complete" -- it follows)
+    if (s != side_of_caller && (rcd = stream_dep(p, s, side_of_caller))) return rcd;
     return WUN_OK;
 }
 
@@ -1355,18 +1378,7 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
         if (narrow_wgrad_supported(nw) && (p->bf16 || getenv("WUN_NO_NARROW") == nullptr)) {
             long long woff[4] = {0, 0, 0, 0}, boff[4] = {0, 0, 0, 0};
             for (int sh = 0; sh < p->Sh; ++sh) { woff[sh] = p->head[sh].woff; boff[sh] = p->head[sh].boff; }
-            hipStream_t hs = wstream();
-            if ((rc = run_narrow_wgrad(p, &nw, 1, woff, boff, ws, grads, s, hs))) return rc;
-            // bf16 mode: the OTHER side stream starts after this launch.  Measured (round 5, tools/repro_probe.py):
-            // with ragged rows (context: 16389 output positions) the head's kernel gradient came out different by 1e-5 .. 3e-4
-            // of max|g| in 10 - 100 % of the steps of a process -- whole 64-byte lines of narrow_wgrad_kernel's split partials
-            // read back wrong by its reduction -- if and only if the up level's wgrad_bf16_kernel (other side stream) ran beside
-            // it; every other tensor of the step stayed bit-identical, the exact-fp32 mode and same-padding shapes never showed
-            // it, nor did this order (3 x 8 steps) or the launch on the caller's stream (2 x 8).  Root cause not found (no buffer
-            // of the two launches overlaps, LDS contents and staged inputs verified inside the kernel); the order costs the
-            // dependent chain nothing (no packet on `stream`) and the side stream one ~30 us launch
-            if (p->bf16 && s3 != s2 && hs != s && getenv("WUN_BF16_HEAD_OVERLAP") == nullptr &&
-                (rc = stream_dep(p, hs, hs == s2 ? s3 : s2))) return rc;
+            if ((rc = run_narrow_wgrad(p, &nw, 1, woff, boff, ws, grads, s, wstream()))) return rc;
             head_done = true;
         } else if (p->bf16) {
             // bf16 mode: the head's inputs are the fp32 audio and the bf16 feature map -- only the narrow kernels read
