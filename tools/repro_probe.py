@@ -70,6 +70,22 @@ for r in range(NREP):
                          float((a - b).abs().max() / max(b.abs().max().item(), 1e-30))))
     nbad += bool(diffs)
     if len(diffs) > 6:
-        diffs = diffs[:6] + ["... %d tensors in all" % len(diffs)]
+        # a whole-step event: name the first tensors that differ in EXECUTION order (forward: dec_i / skip_i per level,
+        # bottleneck, ups_j / up_j per up level; then the backward pass in reverse)
+        L = 12
+        order = []
+        for i in range(L): order += ["dec%d" % i, "skip%d" % i]
+        order += ["bottleneck"]
+        for j in range(L): order += ["ups%d" % j, "up%d" % j]
+        order += [k for k in ref if k.startswith("o:")] + ["loss"]
+        for j in range(L - 1, -1, -1): order += ["dz_up%d" % j, "dz_skip%d" % (L - 1 - j), "d_ups%d" % j]
+        order += ["dz_bottleneck"] + ["dz_dec%d" % i for i in range(L - 1, -1, -1)]
+        first = [k for k in order if k in ref and not torch.equal(got[k], ref[k])][:4]
+        firstd = []
+        for k in first:
+            a, b = got[k].double(), ref[k].double()
+            nz = (a != b).nonzero()
+            firstd.append("%s: %d of %d differ, first at %s, last at %s" % (k, nz.shape[0], a.numel(), nz[0].tolist(), nz[-1].tolist()))
+        diffs = ["FIRST IN EXECUTION ORDER: " + " ; ".join(firstd)] + diffs[:4] + ["... %d tensors in all" % len(diffs)]
     print("[%s %s] repeat %d: %s" % (which, dt, r, "bitwise identical" if not diffs else " | ".join(diffs)), flush=True)
 print("[%s %s] %d of %d repeats differ from the first run" % (which, dt, nbad, NREP))
