@@ -347,7 +347,6 @@ def test_bf16_full_size_m4_baseline_stereo(lib):
     over = dict(output_type="difference", context=True, mono_downmix=False)
     ocfg = shapes.finalize_config(dict(shapes.BASE_MODEL_CONFIG, **over))
     sep = _step(over, ocfg, golden_params(ocfg, 91), 2, 16384, 92, "bf16_M4_baseline_stereo_full_B2")
-    # bit-determinism is kept in the speed mode too
     assert sep.plan_info().output_frames == 16389
 
 
