@@ -399,11 +399,14 @@ def test_m4_context_step_is_bit_reproducible_across_fresh_separators(lib, dtype)
     """BASELINE.json configs[2] (M4: context, stereo, difference output; 147443 -> 16389 samples, ragged rows) on six fresh
     separators of this process, after the other tests' plans: loss, outputs and every gradient tensor bitwise equal.
     Round 5 found the bf16 mode's head weight gradient moving by 1e-5 .. 8e-4 of max|g| between such runs (10 - 100 % of
-    the steps, depending on the process) whenever bf16 MFMA kernels ran beside narrow_wgrad_kernel; that launch now runs
-    alone (run_narrow_wgrad).  tools/repro_probe.py is the stand-alone form.
-    exact-fp32 mode: all six identical.  bf16 mode: at most ONE of the six may differ -- the same probe also caught, twice in
-    ~300 steps, a step whose FORWARD pass already differed (every tensor off by 1e-7 .. 1e-4, cause open, DESIGN 5g(9));
-    the defect this test guards against showed in 2 .. 6 of 6."""
+    the steps, depending on the process) whenever bf16 MFMA kernels ran beside narrow_wgrad_kernel: its packed fp32 VALU
+    instructions miscomputed there (identical LDS tiles, different accumulators).  The bf16 mode's translation units are now
+    built without them and that launch runs alone (csrc/Makefile NO_PK_FP32, run_narrow_wgrad, DESIGN.md 5g(9));
+    tools/repro_probe.py is the stand-alone form.
+    exact-fp32 mode: all six identical.  bf16 mode: at most ONE of the six may differ -- before the rebuild the same probe
+    also caught one step in ~770 whose FORWARD pass already differed (every tensor off by 1e-7 .. 1e-4; the shared elementwise
+    kernels of wun_kernels.hip still carry packed instructions, DESIGN 5g(9) "still open"); the defect this test guards
+    against showed in 2 .. 6 of 6."""
     over = dict(output_type="difference", context=True, mono_downmix=False)
     ocfg = shapes.finalize_config(dict(shapes.BASE_MODEL_CONFIG, **over))
     params = golden_params(ocfg, 91)

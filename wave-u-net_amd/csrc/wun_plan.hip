@@ -1175,14 +1175,13 @@ static int run_narrow_wgrad(const wun_plan* p, NarrowWgradArgs* parts, int npart
     // bf16 mode: narrow_wgrad_kernel (the LDS-staged form: the output head, audio-input convs with < 4 taps) runs ALONE on the
     // device -- on the caller's stream, after whatever the side streams still hold.  Measured (round 5, tools/repro_probe.py,
     // DESIGN 5g(9)): with ragged rows (context: 16389 output positions) the head's kernel gradient came out different by
-    // 1e-5 .. 8e-4 of max|g| in 10 - 100 % of the steps of a process -- runs of 16 elements, once exactly the contribution of
-    // the last position of 8 channels -- whenever the up level's wgrad_bf16_kernel (other side stream) ran beside it, and once
-    // in 24 steps with only that stream held back (the dependent chain's conv_bf16_kernel still beside it); every other tensor
-    // of the step stayed bit-identical, the exact-fp32 mode and same-padding shapes never showed it, nor did the launch on
-    // the caller's stream.  Root cause not found (no buffer of the launches overlaps; LDS tiles, staged inputs and reduction
-    // slots verified by canaries inside the kernel).  The head is the first launch of the backward pass that leaves the
-    // caller's stream, so this costs the dependent chain the kernel itself (~30 us per step) and two idle joins.
-    // WUN_BF16_HEAD_OVERLAP=1: the old placement on a side stream.
+    // 1e-5 .. 8e-4 of max|g| in 10 - 100 % of the steps of a process whenever bf16 MFMA kernels ran beside this kernel; every
+    // other tensor of the step stayed bit-identical, the exact-fp32 mode never showed it.  Traced to the kernel's packed fp32
+    // VALU instructions (identical LDS tiles, different accumulators; gone when the translation unit is built without them:
+    // csrc/Makefile, NO_PK_FP32 -- which is how the library is built now).  The placement is kept on top of that for this
+    // round: the head is the first launch of the backward pass that would leave the caller's stream, so it costs the dependent
+    // chain the kernel itself (~30 us per step, ~1 % of the bf16 step) and two idle joins.  WUN_BF16_HEAD_OVERLAP=1: the side
+    // stream again (0 of 24 differing steps with the packed instructions gone, 24 of 24 with them, same boxes).
     if (p->bf16 && s != main && getenv("WUN_BF16_HEAD_OVERLAP") == nullptr) {
         bool lds_form = false;
         for (int i = 0; i < nparts; ++i) lds_form = lds_form || narrow_wgrad_uses_lds(parts[i]);
