@@ -404,9 +404,8 @@ def test_m4_context_step_is_bit_reproducible_across_fresh_separators(lib, dtype)
     built without them and that launch runs alone (csrc/Makefile NO_PK_FP32, run_narrow_wgrad, DESIGN.md 5g(9));
     tools/repro_probe.py is the stand-alone form.
     exact-fp32 mode: all six identical.  bf16 mode: at most ONE of the six may differ -- before the rebuild the same probe
-    also caught one step in ~770 whose FORWARD pass already differed (every tensor off by 1e-7 .. 1e-4; the shared elementwise
-    kernels of wun_kernels.hip still carry packed instructions, DESIGN 5g(9) "still open"); the defect this test guards
-    against showed in 2 .. 6 of 6."""
+    also caught one step in ~770 whose FORWARD pass already differed (every tensor off by 1e-7 .. 1e-4; DESIGN 5g(9) "still
+    open": not enough probe steps since the rebuild to call it gone); the defect this test guards against showed in 2 .. 6 of 6."""
     over = dict(output_type="difference", context=True, mono_downmix=False)
     ocfg = shapes.finalize_config(dict(shapes.BASE_MODEL_CONFIG, **over))
     params = golden_params(ocfg, 91)

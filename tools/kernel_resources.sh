@@ -1,6 +1,7 @@
 #!/bin/bash
-# Register / scratch usage of every kernel of wun_kernels.hip (device-only compile for gfx950; no GPU needed).
-# usage: tools/kernel_resources.sh [extra hipcc flags]   -> table on stdout
+# Register / scratch usage of every kernel of one translation unit (device-only compile for gfx950; no GPU needed).
+# usage: [SRC=wun_bf16.hip] tools/kernel_resources.sh [extra hipcc flags]   -> table on stdout   (default SRC: wun_kernels.hip;
+# the bf16 mode's units and wun_elementwise.hip are built with: -Xclang -target-feature -Xclang -packed-fp32-ops, csrc/Makefile)
 set -e
 R=$(cd $(dirname $0)/.. && pwd)
 T=$(mktemp -d)
