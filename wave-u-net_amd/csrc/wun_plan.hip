@@ -2100,4 +2100,4 @@ extern "C" int wun_abi_sizes(int64_t* sizes, int n) {
 }
 
 extern "C" const char* wun_last_error(void) { return g_err.c_str(); }
-extern "C" const char* wun_version(void) { return "wun 0.4 (gfx950, fp32 MFMA 16x16x4 + bf16 MFMA 16x16x32 speed mode)"; }
+extern "C" const char* wun_version(void) { return "wun 0.5 (gfx950, fp32 MFMA 16x16x4 + bf16 MFMA 16x16x32 speed mode)"; }
