@@ -101,3 +101,36 @@ def test_layerwise_mode_is_a_fixed_point_on_its_own_tensors(name):
     assert torch.equal(inter3["dec0"], inter["dec0"])                 # computed from the audio, which did not change
     assert not torch.equal(inter3["dec1"], inter["dec1"])             # reads dec0
     assert torch.equal(inter3["bottleneck"], inter["bottleneck"])     # reads the (given) dec2
+
+
+def test_wide_head_rounds_only_the_heads_weight_gradient_operands():
+    """(C + F) * Sh * C > 256 (the deep variant's head: stereo, 48 filters, 3 trained sources): the plan runs the head's weight
+    gradient on the bf16 MFMA kernel, on bf16 copies of the audio and of d(pre-activation) -- everything else of the step is
+    the narrow-head computation, so the two emulations may differ in the head kernels' gradients only, and there by bf16
+    rounding of the operands (a few 1e-3), not more."""
+    over = dict(num_layers=2, num_initial_filters=48, mono_downmix=False, task="multi_instrument", output_type="difference")
+    cfg = shapes.finalize_config(dict(shapes.BASE_MODEL_CONFIG, **over))
+    assert bf16_emul.head_on_mfma(cfg)
+    params = golden_params(cfg, 7)
+    mix, targets = wt.synthetic_batch(cfg, 2, 256, 256, seed=8)
+    loss_w, grads_w, inter_w = bf16_emul.train_step(cfg, params, mix, targets)
+    orig = bf16_emul.head_on_mfma
+    bf16_emul.head_on_mfma = lambda c: False
+    try:
+        loss_n, grads_n, inter_n = bf16_emul.train_step(cfg, params, mix, targets)
+    finally:
+        bf16_emul.head_on_mfma = orig
+    assert loss_w == loss_n
+    for k in inter_w:
+        if k not in ("outputs", "_scale"):
+            assert torch.equal(inter_w[k], inter_n[k]), k
+    nvar = len(params)
+    head = set(range(nvar - 6, nvar))                                   # three head convs: kernel + bias each
+    for i, ((n, _), a, b) in enumerate(zip(params, grads_w, grads_n)):
+        if i in head:
+            rel = (a - b).norm().item() / max(b.norm().item(), 1e-30)
+            assert rel < 2e-2, (n, rel)
+            if n.endswith("/kernel"):
+                assert rel > 1e-5, (n, rel)                             # ... and the rounding IS there
+        else:
+            assert torch.equal(a, b), n
