@@ -76,8 +76,8 @@ def usable_cores():
 
 # committed, READ-ONLY tuning tables per (named config, batch, dtype); never used as a writable cache
 PINNED_TUNE_TABLES = {
-    ("m1_context", 16, "f32"): os.path.join(ROOT, "profiles", "round5_tune_table.txt"),
-    ("baseline", 16, "f32"): os.path.join(ROOT, "profiles", "round5_tune_table_baseline.txt"),
+    ("m1_context", 16, "f32"): os.path.join(ROOT, "profiles", "round6_tune_table.txt"),
+    ("baseline", 16, "f32"): os.path.join(ROOT, "profiles", "round6_tune_table_baseline.txt"),
 }
 PINNED_TUNE_TABLE = PINNED_TUNE_TABLES[("m1_context", 16, "f32")]
 
@@ -163,7 +163,7 @@ def pmc_traffic(family, table_text):
     if that summary was collected with the very tuning table this run executes (its sha is stored
     beside the numbers); PMC counters cannot be collected from inside this process.  Else None."""
     import hashlib
-    path = os.path.join(ROOT, "profiles", "round5_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "round6_pmc_traffic.json")
     try:
         doc = json.load(open(path))
     except Exception:
@@ -412,7 +412,9 @@ def main():
         "ms_median": float(np.median(step_ms)), "ms_p10": float(np.percentile(step_ms, 10)),
         "ms_p90": float(np.percentile(step_ms, 90)), "ms_max": float(step_ms.max()),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.dtype == "f32" else "bf16 (activations and their gradients in HBM + all MFMA operands; fp32 accumulate, weights, weight gradients, Adam)",
+        # (the arithmetic that actually ran: a config that asks for bf16 without qualifying gets the exact-fp32 plan --
+        #  wun_plan_info.compute_dtype_effective)
+        "dtype": "f32" if int(info.compute_dtype_effective) == 0 else "bf16 (activations and their gradients in HBM + all MFMA operands; fp32 accumulate, weights, weight gradients, Adam)",
         "data": "synthetic",
         "config": {"workload": ("BASELINE.json configs[1]: M1 (12 levels, 24 ch, 15/5 filters, mono) with context, "
                                 "fwd+bwd+Adam, batch %d/GPU, %d -> %d samples" % (tr.batch, tr.t_in, tr.t_out))
@@ -429,6 +431,10 @@ def main():
                    "tilings": tilings, "settle_steps": settle_steps,
                    "forced_allreduce": bool(forced), "bucket_mib": args.bucket_mib,
                    "step_tflops_executed": step_flops / 1e12,
+                   # every observed conv output computed once (== executed since round 6 for the exact-fp32 mode: the
+                   # skip windows' even positions are no longer computed twice; the bf16 mode's context plans still do)
+                   "step_tflops_nonredundant": (info.fwd_flops_unique + info.bwd_flops_unique) / 1e12,
+                   "requested_dtype": args.dtype,
                    "step_tflops_reference_graph": 3.0 * info.fwd_flops_dense / 1e12,
                    "achieved_tflops_executed": step_flops / (ms_per_step * 1e9),
                    "step_frac_of_fp32_mfma_peak": step_flops / (ms_per_step * 1e9) / PEAK_FP32_MFMA_TFLOPS},
@@ -446,6 +452,10 @@ def main():
         ndiag = max(3, min(10, args.steps))
         overlapped = hasattr(reducer, "begin")
         exposed = []
+        # The diagnostic steps are NOT training: the no-comm ones apply un-reduced (per-rank) gradients, which would leave the
+        # replicas' parameters divergent for everything that follows.  Parameters, both Adam slots and the
+        # step counter are snapshotted here and restored after the block.
+        snap = (tr.sep.params.clone(), tr.sep.adam_m.clone(), tr.sep.adam_v.clone(), tr.sep.global_step)
         for _ in range(ndiag):
             tr.sep.get_output(mix, True)
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -482,6 +492,10 @@ def main():
                           "overlapped": bool(overlapped), "exposed_ms": float(stats[0].item()), "diagnostic_steps": ndiag,
                           "backend": dist.get_backend() if dist.is_initialized() else None}
         result["ms_per_step_no_comm"] = float(stats[1].item())
+        result["comm"]["note"] = "diagnostic steps are not training: parameters / Adam state restored afterwards"
+        tr.sep.params.copy_(snap[0]); tr.sep.adam_m.copy_(snap[1]); tr.sep.adam_v.copy_(snap[2]); tr.sep.global_step = snap[3]
+        del snap
+        torch.cuda.synchronize()
         log("comm: %d buckets, %.1f MB, exposed %.3f ms/step; step without the all-reduce %.3f ms" % (
             len(reducer.buckets), result["comm"]["bytes"] / 1e6, result["comm"]["exposed_ms"], no_comm_ms))
 

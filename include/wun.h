@@ -95,6 +95,13 @@ typedef struct wun_plan_info {
     double  fwd_flops;          /* algorithmic conv FLOPs / step as executed (dead work skipped) */
     double  bwd_flops;
     double  fwd_flops_dense;    /* the reference graph's FLOPs (no dead-work skipping)       */
+    double  fwd_flops_unique;   /* every OBSERVED conv output computed once.  == fwd_flops for same-padding plans and for  */
+    double  bwd_flops_unique;   /* context plans of the exact-fp32 mode (round 6); the bf16 mode's context plans still run */
+                                /* a full-rate conv over each skip window, i.e. compute its even positions twice           */
+    int64_t compute_dtype_effective; /* the arithmetic the plan really runs: 0 = exact fp32, 1 = bf16 mode.  A config that   */
+                                /* asks for compute_dtype = 1 but does not qualify (num_initial_filters % 8 != 0, a      */
+                                /* tap-less conv phase, rows beyond the bf16 kernels' 32-bit offsets) gets the exact-fp32 */
+                                /* plan and reports 0 here -- callers label their results with THIS value.                */
 } wun_plan_info;
 
 typedef struct wun_tensor_info {
@@ -238,6 +245,19 @@ int wun_op_conv1d_ex(const float* x0, int c0, const float* x1, int c1, const flo
                      float* y, const float* mask, int batch, int cout, int k, int t_in, int t_out,
                      int t_y, int stride, int pad_left, int lrelu, int accumulate, int ostride, int ooff,
                      void* stream);
+
+/* Test hook for the secondary outputs of the plan's conv launch (round 6: a context plan computes every conv output once --
+ * the decimated stream is a slice of the encoder output, UnetAudioSeparator.py:98-100).  Every following wun_op_conv1d_ex
+ * launch also writes
+ *   copy0 [B][cout][t0]: expand = 0: the compact copy of its EVEN outputs, copy0[b][n][q / 2] (same-padding down levels);
+ *                        expand = 1: output q at copy0[b][n][2q - exp_lo] where 0 <= 2q - exp_lo < exp_len (the stride-2
+ *                        launch of a down level writing the even positions of the skip window);
+ *   copy1 [B][cout][t1]: the compact copy of its ODD outputs, copy1[b][n][q / 2] (an up level's input gradient splitting
+ *                        the skip window's gradient by parity);
+ * and, when acc_len > 0, `accumulate` applies only to the row positions ooff + q*ostride inside [acc_lo, acc_lo + acc_len)
+ * (stored elsewhere).  NULL pointers / acc_len = 0 switch each part off; wun_op_set_conv_copies(0,0,0,0,0,0,0,0,0) resets. */
+int wun_op_set_conv_copies(float* copy0, int t0, int expand, int exp_lo, int exp_len, float* copy1, int t1,
+                           int acc_lo, int acc_len);
 
 /* Test hook: force the tile variant (index into the kernel's variant table, -1 = automatic) and
  * split-K factor (0 = automatic) of every following wun_op_conv1d / _ex / _dgrad launch, so the parity

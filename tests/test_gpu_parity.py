@@ -322,14 +322,16 @@ def _gpu_pins(sep, ocfg):
     workspace (wun_plan_activation), as `pins` for the oracle (oracle/waveunet_torch.py: leaky_relu): name -> (pos, known)
     bool tensors of the layer's full conv-output shape.  Post-activation values keep the pre-activation's sign, so
     pos = (stored value > 0).  A down level keeps two tensors -- the decimated stream (even positions, what the next
-    level reads) and the skip window (what crop_and_concat reads); with context they come from two launches whose
-    summation orders differ, so the same conv output can sit on different sides of 0 in the two: "down<i>" pins the
-    value the skip connection sees, "down<i>/dec" the value the decimation sees.  Positions the kernels never compute
-    (odd outputs outside the crop window, context mode: dead work) stay unpinned."""
+    level reads) and the skip window (what crop_and_concat reads).  Since round 6 the decimated stream IS a slice of the
+    encoder output, as in the reference (UnetAudioSeparator.py:98-100): the even window positions are written once, by the
+    stride-2 launch, into both tensors -- asserted here bit for bit -- so ONE pin per level, "down<i>", covers both (rounds
+    1 - 5 computed them twice with different summation orders and needed a separate "down<i>/dec" pin).  Positions the
+    kernels never compute (odd outputs outside the crop window, context mode: dead work) stay unpinned."""
     L, same = ocfg["num_layers"], not ocfg["context"]
     Kd = ocfg["filter_size"]
     B = int(sep._active.info.batch)
     t = int(sep._active.info.input_frames)
+    assert sep.effective_dtype == "f32"
     pins = {}
 
     def place(shape, view, t0, tstep):
@@ -345,11 +347,19 @@ def _gpu_pins(sep, ocfg):
         t_conv = t if same else t - Kd + 1
         v, t0, ts = sep.activation("skip", i)
         shape = (B, v.shape[1], t_conv)
-        pins["down%d" % i] = place(shape, v, t0, ts)
+        pos, known = place(shape, v, t0, ts)
         if not same:
             vd, t0d, tsd = sep.activation("dec", i)
-            assert (t0d, tsd) == (0, 2) and vd.shape[2] == (t_conv + 1) // 2
-            pins["down%d/dec" % i] = place(shape, vd, t0d, tsd)
+            assert (t0d, tsd) == (0, 2) and vd.shape[2] == (t_conv + 1) // 2 and ts == 1
+            # the even absolute positions of the window are the decimated stream's elements: same bits
+            e0 = t0 + (t0 & 1)
+            n_even = len(range(e0, t0 + v.shape[2], 2))
+            if n_even:
+                assert torch.equal(v[:, :, e0 - t0::2].cpu(), vd[:, :, e0 // 2:e0 // 2 + n_even].cpu()), \
+                    "down level %d: skip window and decimated stream disagree at the shared positions" % i
+            pd, kd = place(shape, vd, t0d, tsd)
+            pos, known = torch.where(known, pos, pd), known | kd
+        pins["down%d" % i] = (pos, known)
         t = (t_conv + 1) // 2
     v, t0, ts = sep.activation("bottleneck")
     pins["bottleneck"] = place(tuple(v.shape), v, t0, ts)
@@ -837,13 +847,13 @@ def test_tuned_plan_error_is_the_leaky_relu_sign_floor(lib):
 def test_benchmarked_configuration_b16_tuned_vs_oracle(lib):
     """EXACTLY what bench.py times -- BASELINE.json configs[1]: M1 with context, batch 16,
     147443 -> 16389 samples, the Trainer's seed-1337 weights, the synthetic_source(seed 1337) batch
-    and the tilings bench.py runs (the committed table profiles/round5_tune_table.txt, handed to
+    and the tilings bench.py runs (the committed table profiles/round6_tune_table.txt, handed to
     Trainer.tune as read-only text, when it matches this build; a fresh wun_plan_tune otherwise) -- compared element
     by element with the FLOAT64 oracle: outputs, loss and all 54 gradient tensors of the whole batch
     (the oracle runs one excerpt at a time and averages: the loss is a mean over excerpts)."""
     from wave_u_net_amd.training import Trainer, synthetic_source
     cfg = wun.get_config("m1_context")
-    table = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "round5_tune_table.txt")
+    table = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "round6_tune_table.txt")
     text = open(table).read() if os.path.exists(table) else None
     before = text
     tr = Trainer(cfg, batch_size=16)

@@ -218,6 +218,102 @@ def test_conv_every_variant_strided_output(lib, case):
     record("conv_every_variant_strided_output", str(case), worst[0], OP_TOL)
 
 
+_COPY_CASES = SWEEP_CASES[:4] + SWEEP_CASES[5:7] + SWEEP_CASES[12:14]
+
+
+@pytest.mark.parametrize("case", _COPY_CASES, ids=[str(c) for c in _COPY_CASES])
+@pytest.mark.parametrize("mode", ["expand_stride2", "parity_split_masked", "acc_window"])
+def test_conv_every_variant_secondary_copies(lib, case, mode):
+    """Round 6 (a context plan computes every conv output ONCE: the decimated stream is a slice of the encoder output,
+    UnetAudioSeparator.py:98-100) -- the epilogue features behind it, on every tile variant x split-K through the
+    wun_op_set_conv_copies hook:
+      expand_stride2      a stride-2 conv that also writes output q at copy0[2q - lo] inside a window (the decimating launch
+                          writing the even positions of the skip window): bit-equal to the main output there, untouched elsewhere;
+      parity_split_masked a stride-1 launch with a LeakyReLU-derivative mask whose EVEN outputs are also stored compactly in
+                          copy0 and whose ODD outputs in copy1 (an up level's input gradient splitting the skip window's
+                          gradient by parity): both bit-equal to the main output;
+      acc_window          accumulate only inside [lo, lo + len) of the row, store elsewhere (the transposed conv that fills
+                          a gradient row which already holds the even half of the window's gradient)."""
+    B, Cin, Cout, K, T, same = case
+    rng = np.random.default_rng(abs(hash((case, mode))) % (2 ** 31) + 11)
+    x = rng.uniform(-1, 1, (B, Cin, T)).astype(np.float32)
+    w = (rng.uniform(-1, 1, (K, Cin, Cout)) / np.sqrt(K * Cin)).astype(np.float32)
+    stride = 2 if mode == "expand_stride2" else 1
+    if stride == 2 and same:
+        pytest.skip("the plan only uses the stride-2 loader with valid padding")
+    pad = (K - 1) // 2 if same else 0
+    t_out = _t_out(T, K, stride, same)
+    if t_out < 6:
+        pytest.skip("row too short for a window")
+    conv = _conv64(x, w, None, stride, pad, t_out).numpy()
+    dx, dw = _cuda(x), _cuda(w)
+    y = torch.empty((B, Cout, t_out), device="cuda")
+    worst = [0.0]
+    POISON = -7.25
+    if mode == "expand_stride2":
+        lo, ln = 2 * (t_out // 4) + 1, max(3, t_out // 2) | 1          # an odd window start, odd length
+        c0 = torch.empty((B, Cout, ln), device="cuda")
+        ref = np.maximum(0.2 * conv, conv)
+        args = (c0.data_ptr(), ln, 1, lo, ln, None, 0, 0, 0)
+        acc_flag, mask_ptr, lrelu = 0, None, 1
+    elif mode == "parity_split_masked":
+        fwd = rng.uniform(-1, 1, (B, Cout, t_out)).astype(np.float32)
+        dmask = _cuda(fwd)
+        ref = conv * np.where(fwd > 0, 1.0, 0.2)
+        ne, no = (t_out + 1) // 2, t_out // 2
+        c0 = torch.empty((B, Cout, ne), device="cuda")
+        c1 = torch.empty((B, Cout, max(no, 1)), device="cuda")
+        args = (c0.data_ptr(), ne, 0, 0, 0, c1.data_ptr(), max(no, 1), 0, 0)
+        acc_flag, mask_ptr, lrelu = 0, dmask.data_ptr(), 0
+    else:
+        base = rng.uniform(-1, 1, (B, Cout, t_out)).astype(np.float32)
+        dbase = _cuda(base)
+        lo, ln = t_out // 3 + 1, max(2, t_out // 3)
+        ref = conv.copy()
+        ref[:, :, lo:lo + ln] += base[:, :, lo:lo + ln].astype(np.float64)
+        args = (None, 0, 0, 0, 0, None, 0, lo, ln)
+        acc_flag, mask_ptr, lrelu = 1, None, 0
+    scale = max(1.0, np.abs(ref).max())
+
+    def launch():
+        if mode == "acc_window":
+            y.copy_(dbase)
+        else:
+            y.fill_(float("nan"))
+            c0.fill_(POISON)
+            if mode == "parity_split_masked":
+                c1.fill_(POISON)
+        _lib.check(lib.wun_op_set_conv_copies(*args))
+        try:
+            return lib.wun_op_conv1d_ex(dx.data_ptr(), Cin, None, 0, dw.data_ptr(), None, y.data_ptr(), mask_ptr, B, Cout, K,
+                                        T, t_out, t_out, stride, pad, lrelu, acc_flag, 1, 0, _stream())
+        finally:
+            lib.wun_op_set_conv_copies(None, 0, 0, 0, 0, None, 0, 0, 0)
+
+    def check(v, ks):
+        got = y.cpu().numpy()
+        assert np.isfinite(got).all(), (v, ks)
+        err = np.abs(got - ref).max() / scale
+        worst[0] = max(worst[0], err)
+        assert err <= OP_TOL, (v, ks, err)
+        if mode == "expand_stride2":
+            g0 = c0.cpu().numpy()
+            exp = np.full(g0.shape, POISON, dtype=np.float32)
+            for q in range(t_out):
+                pos = 2 * q - lo
+                if 0 <= pos < ln:
+                    exp[:, :, pos] = got[:, :, q]
+            assert np.array_equal(g0, exp), (v, ks)                       # same bits where written, untouched elsewhere
+        elif mode == "parity_split_masked":
+            assert np.array_equal(c0.cpu().numpy()[:, :, :ne], got[:, :, 0::2]), (v, ks)
+            if no:
+                assert np.array_equal(c1.cpu().numpy()[:, :, :no], got[:, :, 1::2]), (v, ks)
+
+    ran = _sweep(lib, "copies_" + mode, launch, check)
+    assert ran >= 2
+    record("conv_every_variant_secondary_copies", "%s %s" % (mode, case), worst[0], OP_TOL)
+
+
 PHASE2_CASES = [
     # (B, Cin, Cout, K, T_in): input gradient of a stride-2 valid conv; Cin (the GEMM N) decides which
     # fused two-phase tiles (32/64/96 columns = 16/32/48 channels x 2 phases) are legal

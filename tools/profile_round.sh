@@ -7,7 +7,7 @@ tag=${1:-round}
 R=$PWD
 mkdir -p gpurun_out
 # tilings: bench.py imports the committed pinned table of the config by itself (read-only); PINNED=0 -> fresh tuning
-PIN=$R/profiles/round5_tune_table.txt
+PIN=$R/profiles/round6_tune_table.txt
 if [ "${PINNED:-1}" != 1 ]; then
     export WUN_TUNE_CACHE=$R/gpurun_out/${tag}_tune_table.txt
     [ "${KEEP_TUNE:-0}" = 1 ] || rm -f $WUN_TUNE_CACHE
@@ -47,7 +47,11 @@ cd $R
 if [ "${CFGS:-1}" = 1 ]; then
     unset WUN_TUNE_CACHE
     for c in baseline baseline_stereo full full_multi_instrument; do
-        python bench.py --config $c --no-cpu-baseline > gpurun_out/${tag}_cfg_${c}_f32.json 2> gpurun_out/${tag}_cfg_${c}_f32.err
+        # configs[0] (SURVEY 8d's PR1 CPU-baseline config) and configs[2] carry `cpu_baseline` and `parity` like the headline
+        # line (~1 s / ~3 s of CPU work each); the others skip the CPU leg
+        nocpu=--no-cpu-baseline
+        case $c in baseline|baseline_stereo) nocpu= ;; esac
+        python bench.py --config $c $nocpu > gpurun_out/${tag}_cfg_${c}_f32.json 2> gpurun_out/${tag}_cfg_${c}_f32.err
         python bench.py --config $c --dtype bf16 --no-cpu-baseline > gpurun_out/${tag}_cfg_${c}_bf16.json 2> gpurun_out/${tag}_cfg_${c}_bf16.err
     done
     python bench.py --dtype bf16 --no-cpu-baseline > gpurun_out/${tag}_cfg_m1_context_bf16.json 2> gpurun_out/${tag}_cfg_m1_context_bf16.err

@@ -6,7 +6,7 @@ the M4 configuration (BASELINE.json configs[2]: context + stereo + difference ou
 times on fresh separators and compares loss, outputs, every gradient tensor and every tensor the step leaves in the
 workspace (wun_plan_activation kinds 0 - 9) BITWISE with the first run.  This is the probe that found the bf16 mode's
 head weight gradient differing from run to run when wgrad_bf16_kernel ran beside narrow_wgrad_kernel (DESIGN.md 5g);
-WUN_BF16_HEAD_OVERLAP=1 restores that launch order.
+(the library built WITH packed fp32 ops: make -C wave-u-net_amd/csrc pkdiag; WUN_LIB=libwun_pk.so shows the defect again; WUN_BF16_HEAD_SERIAL=1 is round 5's serialised placement).
 usage: python tools/repro_probe.py [bf16|f32] [m4|m4_same|m1_context|m5|multi|multi_direct]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -19,7 +19,8 @@ class WunPlanInfo(C.Structure):
                 ("num_params", C.c_int64), ("arena_floats", C.c_int64),
                 ("workspace_floats", C.c_int64), ("num_tensors", C.c_int64),
                 ("num_outputs", C.c_int64), ("fwd_flops", C.c_double), ("bwd_flops", C.c_double),
-                ("fwd_flops_dense", C.c_double)]
+                ("fwd_flops_dense", C.c_double), ("fwd_flops_unique", C.c_double),
+                ("bwd_flops_unique", C.c_double), ("compute_dtype_effective", C.c_int64)]
 
 
 class WunActivationInfo(C.Structure):
@@ -65,6 +66,7 @@ _SIGS = {
     "wun_op_set_wgrad_win": (C.c_int, [C.c_int]),
     "wun_op_set_wgrad_narrow": (C.c_int, [C.c_int]),
     "wun_op_conv1d_ex": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, _P, _P] + [C.c_int] * 12 + [_P]),
+    "wun_op_set_conv_copies": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
     "wun_profile_begin": (C.c_int, []),
     "wun_profile_end": (C.c_int, [C.c_char_p, C.c_int64]),
     "wun_abi_sizes": (C.c_int, [C.POINTER(C.c_int64), C.c_int]),

@@ -42,6 +42,15 @@ struct ConvArgs {
     int ostride;
     int Tout;
     float* dec; long long decbs; int decpitch;
+    // Round 6 (context plans of the exact-fp32 mode: the decimated stream IS a slice of the encoder output,
+    // UnetAudioSeparator.py:98-100, computed once): two more copies of dst0, same validity rules as `dec`.
+    //   dec_exp != 0: `dec` is an EXPANDED copy instead of a compact one -- output q goes to dec[b][n][2q - dec_lo] when
+    //                 0 <= 2q - dec_lo < dec_len (the stride-2 conv of a down level writes the even positions of the skip window);
+    //   dec1        : compact copy of the ODD q of dst0, dec1[b][n][q >> 1] (an up level's input gradient splits the skip
+    //                 window's gradient by the parity of the absolute conv position: one half is added to the decimated
+    //                 stream's gradient, the other feeds the odd-position launches).
+    int dec_exp; int dec_lo; unsigned dec_len;
+    float* dec1; long long dec1bs; int dec1pitch;
     int flags;
     int B;
     int loader;

@@ -198,6 +198,38 @@ __device__ __forceinline__ int fast_div(int n, int d, float inv) {
 // [0, Tin) ('same' padding, the halo of a transposed conv) are zeroed in LDS after the DMA has landed, by the edge
 // tiles only.  The element-wise register path stays for the stride-2 loader, FOLD tiles, channel tails and
 // unaligned test tensors.
+// copies of a dst0 output element / quad beside its main store (ConvArgs.dec / dec_exp / dec1): b = excerpt, n = dst0 channel
+__device__ __forceinline__ void conv_copy1(const ConvArgs& a, int b, int n, int q, float v) {
+    if (a.dec != nullptr) {
+        float* row = a.dec + (long long)b * a.decbs + (long long)n * a.decpitch;
+        if (a.dec_exp) {
+            const unsigned pos = (unsigned)(2 * q - a.dec_lo);
+            if (pos < a.dec_len) row[pos] = v;
+        } else if ((q & 1) == 0) {
+            row[q >> 1] = v;
+        }
+    }
+    if (a.dec1 != nullptr && (q & 1) != 0) a.dec1[(long long)b * a.dec1bs + (long long)n * a.dec1pitch + (q >> 1)] = v;
+}
+__device__ __forceinline__ void conv_copy4(const ConvArgs& a, int b, int n, int q, f32x4 v) {       // q % 4 == 0, all four valid
+    if (a.dec != nullptr) {
+        float* row = a.dec + (long long)b * a.decbs + (long long)n * a.decpitch;
+        if (a.dec_exp) {
+            const int pos0 = 2 * q - a.dec_lo;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if ((unsigned)(pos0 + 2 * r) < a.dec_len) row[pos0 + 2 * r] = v[r];
+        } else {
+            row[q >> 1] = v[0];
+            row[(q >> 1) + 1] = v[2];
+        }
+    }
+    if (a.dec1 != nullptr) {
+        float* row = a.dec1 + (long long)b * a.dec1bs + (long long)n * a.dec1pitch;
+        row[q >> 1] = v[1];
+        row[(q >> 1) + 1] = v[3];
+    }
+}
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
 // KG > 1 ("in-workgroup split-K", the deep levels): the workgroup is KG groups of 256 threads; group kg runs the whole
@@ -817,8 +849,7 @@ __global__ __launch_bounds__(256 * KG) void conv_mfma_kernel(ConvArgs a, int nTT
             rowbase = (long long)b * a.obs1 + (long long)(ncol - a.N0) * a.opitch1 + a.ooff1;
             dst = a.dst1; msk = a.msk1;
         }
-        float* decrow = (a.dec != nullptr && ncol < a.N0)
-                            ? a.dec + (long long)b * a.decbs + (long long)ncol * a.decpitch : nullptr;
+        const bool copies = (a.dec != nullptr || a.dec1 != nullptr) && ncol < a.N0;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int q = q0 + wt0 + m * 16 + lg * 4;
@@ -837,8 +868,7 @@ __global__ __launch_bounds__(256 * KG) void conv_mfma_kernel(ConvArgs a, int nTT
                         if (msk != nullptr) v *= (msk[idx] > 0.f) ? 1.f : 0.2f;
                         if (accum && conv_acc_at(a, (first ? a.ooff0 : a.ooff1) + qq * a.ostride)) v += dst[idx];
                         dst[idx] = v;
-                        if (a.dec != nullptr && first && (qq & 1) == 0)
-                            a.dec[(long long)g * a.decbs + (long long)ncol * a.decpitch + (qq >> 1)] = v;
+                        if (copies) conv_copy1(a, g, ncol, qq, v);
                     }
                     if (++qq == a.Tout) { qq = 0; ++g; }
                 }
@@ -863,10 +893,7 @@ __global__ __launch_bounds__(256 * KG) void conv_mfma_kernel(ConvArgs a, int nTT
                         if (conv_acc_at(a, pos0 + r)) v[r] += old[r];
                 }
                 *reinterpret_cast<f32x4*>(&dst[idx]) = v;
-                if (decrow != nullptr) {
-                    decrow[q >> 1] = v[0];
-                    decrow[(q >> 1) + 1] = v[2];
-                }
+                if (copies) conv_copy4(a, b, ncol, q, v);
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -877,7 +904,7 @@ __global__ __launch_bounds__(256 * KG) void conv_mfma_kernel(ConvArgs a, int nTT
                         if (msk != nullptr) v *= (msk[idx] > 0.f) ? 1.f : 0.2f;
                         if (accum && conv_acc_at(a, (ncol < a.N0 ? a.ooff0 : a.ooff1) + (q + r) * a.ostride)) v += dst[idx];
                         dst[idx] = v;
-                        if (decrow != nullptr && ((q + r) & 1) == 0) decrow[(q + r) >> 1] = v;
+                        if (copies) conv_copy1(a, b, ncol, q + r, v);
                     }
                 }
             }
@@ -979,11 +1006,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvArgs a, i
                     if (conv_acc_at(a, pos0 + r)) v[r] += old[r];
             }
             *reinterpret_cast<f32x4*>(&dst[idx]) = v;
-            if (a.dec != nullptr && ncol < a.N0) {
-                float* decrow = a.dec + (long long)b * a.decbs + (long long)ncol * a.decpitch;
-                decrow[q >> 1] = v[0];
-                decrow[(q >> 1) + 1] = v[2];
-            }
+            if ((a.dec != nullptr || a.dec1 != nullptr) && ncol < a.N0) conv_copy4(a, b, ncol, q, v);
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -993,8 +1016,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvArgs a, i
                     if (msk != nullptr) x *= (msk[idx] > 0.f) ? 1.f : 0.2f;
                     if (accum && conv_acc_at(a, pos0 + r * a.ostride)) x += dst[idx];
                     dst[idx] = x;
-                    if (a.dec != nullptr && ncol < a.N0 && ((q + r) & 1) == 0)
-                        a.dec[(long long)b * a.decbs + (long long)ncol * a.decpitch + ((q + r) >> 1)] = x;
+                    if ((a.dec != nullptr || a.dec1 != nullptr) && ncol < a.N0) conv_copy1(a, b, ncol, q + r, x);
                 }
             }
         }

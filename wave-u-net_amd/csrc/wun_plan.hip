@@ -98,7 +98,11 @@ extern "C" int wun_get_padding(const wun_config* cfg, int64_t desired, int64_t* 
 struct Buf { long long off = -1; int C = 0; int T = 0; int pitch = 0; long long bs = 0; int eb = 4; };
 struct ConvLayer { long long woff = 0, boff = 0; int KW = 0, Cin = 0, Cout = 0;
                    long long wt_full = -1, wt_ph[2] = {-1, -1}, wt_ph2 = -1; int Jp[2] = {0, 0}; int J0 = 0; };
-struct DownShape { int cin, cout, t_in, t_conv, t_dec, tc, cs; };
+// tc / cs: length / start of the centre crop the skip connection takes (Utils.py:104-123), in conv-output positions.
+// Round 6 (dedup plans): the crop window split by the parity of the ABSOLUTE conv position -- even positions are elements
+// of the decimated stream (computed once, by the stride-2 launch), odd positions get their own stride-2 launches:
+// t_ev0 / n_even, t_odd0 / n_odd = first position and count of each parity inside [cs, cs + tc).
+struct DownShape { int cin, cout, t_in, t_conv, t_dec, tc, cs, t_ev0, n_even, t_odd0, n_odd; };
 struct UpShape { int c_skip, c_cur, cout, t_cur, t_up, t_conv, crop_start; };
 
 struct wun_plan {
@@ -123,6 +127,15 @@ struct wun_plan {
     Buf mix16;
     long long dpre16_off = -1; int dp16_pitch = 0;
     std::vector<Buf> dec, skip, ups, upo, dz_dec, dz_skip, d_ups, dz_upo;
+    // Round 6, context plans of the exact-fp32 mode ("dedup"): the reference's decimated stream is a SLICE of the encoder
+    // output (UnetAudioSeparator.py:98-100: one tensor, one rounding).  The stride-2 launch of a down level writes its
+    // outputs into dec[i] AND into the even positions of the skip window; a second stride-2 launch computes only the odd
+    // window positions (rounds 1 - 5 ran a stride-1 conv over the whole window: every even window position was computed
+    // twice, 7.8 % of the step's FLOPs).  Backward: an up level's input gradient splits the window's gradient by parity --
+    // even part stored into dz_dec[i] (the transposed conv that fills the rest of dz_dec[i] later ADDS inside that range),
+    // odd part compact in dz_odd[i] -- and the window's input gradient / weight gradient run over the odd positions only.
+    bool dedup = false;
+    std::vector<Buf> dz_odd;
     long long dpre_off = -1; int dp_pitch = 0;
     long long partial_off = -1, partial_floats = 0;
     long long loss_partial_off = -1;
@@ -130,7 +143,7 @@ struct wun_plan {
     std::vector<WtDesc> wt;
     WtDesc* dev_wt = nullptr;
     int wt_max = 0;
-    double fwd_flops = 0, bwd_flops = 0, fwd_dense = 0;
+    double fwd_flops = 0, bwd_flops = 0, fwd_dense = 0, fwd_unique = 0, bwd_unique = 0;
     // second HIP stream: independent launches (weight gradients vs the input-gradient chain;
     // skip-window convs vs the decimating convs) run concurrently so that one kernel's tail and
     // epilogue overlap another kernel's MFMA phase
@@ -280,8 +293,12 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
         t = u.t_conv; ccur = u.cout;
     }
     for (int i = 0; i < L; ++i) {
-        p->dsh[i].tc = p->ush[L - 1 - i].t_up;
-        p->dsh[i].cs = p->ush[L - 1 - i].crop_start;
+        DownShape& d = p->dsh[i];
+        d.tc = p->ush[L - 1 - i].t_up;
+        d.cs = p->ush[L - 1 - i].crop_start;
+        d.t_ev0 = d.cs + (d.cs & 1); d.t_odd0 = d.cs + 1 - (d.cs & 1);
+        d.n_even = d.cs + d.tc > d.t_ev0 ? (d.cs + d.tc - d.t_ev0 + 1) / 2 : 0;
+        d.n_odd = d.tc - d.n_even;
     }
     p->t_feat = t;
     if (p->Tin < p->t_feat) { delete p; return fail(WUN_ERR_INVALID, "crop with negative difference (Utils.py:117)"); }
@@ -312,6 +329,7 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
     // d(pre-activation), weights, weight gradients and all scratch stay fp32)
     p->bf16 = cfg->compute_dtype == 1 && bf16_plan_ok(cfg, B, p->dsh, p->t_b);
     const int eb = p->bf16 ? 2 : 4;
+    p->dedup = !same && !p->bf16 && getenv("WUN_NO_DEDUP") == nullptr;
     p->mix_ncw = make_buf(w, B, C, p->Tin, "mix_ncw");
     p->dec.resize(L); p->skip.resize(L); p->dz_dec.resize(L); p->dz_skip.resize(L);
     for (int i = 0; i < L; ++i) {
@@ -319,6 +337,10 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
         p->skip[i] = make_buf(w, B, p->dsh[i].cout, p->dsh[i].tc, "skip", i, eb);
         if (!same) p->dz_dec[i] = make_buf(w, B, p->dsh[i].cout, p->dsh[i].t_dec, "dz_dec", i, eb);
         p->dz_skip[i] = make_buf(w, B, p->dsh[i].cout, p->dsh[i].tc, "dz_skip", i, eb);
+    }
+    if (p->dedup) {
+        p->dz_odd.resize(L);
+        for (int i = 0; i < L; ++i) p->dz_odd[i] = make_buf(w, B, p->dsh[i].cout, std::max(p->dsh[i].n_odd, 1), "dz_odd", i, eb);
     }
     p->bott_out = make_buf(w, B, p->c_b, p->t_b, "bott_out", 0, eb);
     p->dz_bott = make_buf(w, B, p->c_b, p->t_b, "dz_bott", 0, eb);
@@ -434,8 +456,9 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
         if (same) {
             n = need(wgrad_shape_only(B, d.cin, 0, Kd, LOADER_DIRECT, d.cout, d.t_conv), p->down[i]);
         } else {
-            n = need(wgrad_shape_only(B, d.cin, 0, Kd, LOADER_DEINT, d.cout, d.t_dec), p->down[i]) +
-                need(wgrad_shape_only(B, d.cin, 0, Kd, LOADER_DIRECT, d.cout, d.tc), p->down[i]);
+            n = need(wgrad_shape_only(B, d.cin, 0, Kd, LOADER_DEINT, d.cout, d.t_dec), p->down[i]);
+            if (!p->dedup) n += need(wgrad_shape_only(B, d.cin, 0, Kd, LOADER_DIRECT, d.cout, d.tc), p->down[i]);
+            else if (d.n_odd > 0) n += need(wgrad_shape_only(B, d.cin, 0, Kd, LOADER_DEINT, d.cout, d.n_odd), p->down[i]);
         }
         pmax = std::max(pmax, n);
     }
@@ -451,21 +474,23 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
 
     // ---- FLOP accounting (2*MAC of the conv contractions) ----
     auto cf = [&](int K, double ci, double co, double tt) { return 2.0 * K * ci * co * tt * B; };
-    double fwd = 0, dense = 0, bwd = 0;
+    double fwd = 0, dense = 0, bwd = 0, uniq_f = 0, uniq_b = 0;
     for (int i = 0; i < L; ++i) {
         const DownShape& d = p->dsh[i];
         dense += cf(Kd, d.cin, d.cout, d.t_conv);
-        const double live = same ? cf(Kd, d.cin, d.cout, d.t_conv) : cf(Kd, d.cin, d.cout, d.t_dec) + cf(Kd, d.cin, d.cout, d.tc);
-        fwd += live;
-        bwd += live * (i > 0 ? 2.0 : 1.0);
+        // every observed conv output once: the even positions + the odd positions inside the crop window
+        const double once = same ? cf(Kd, d.cin, d.cout, d.t_conv) : cf(Kd, d.cin, d.cout, d.t_dec) + cf(Kd, d.cin, d.cout, d.n_odd);
+        const double live = (same || p->dedup) ? once : cf(Kd, d.cin, d.cout, d.t_dec) + cf(Kd, d.cin, d.cout, d.tc);
+        fwd += live; uniq_f += once;
+        bwd += live * (i > 0 ? 2.0 : 1.0); uniq_b += once * (i > 0 ? 2.0 : 1.0);
     }
-    { const double f = cf(Kd, p->bott.Cin, p->c_b, p->t_b); fwd += f; dense += f; bwd += 2 * f; }
+    { const double f = cf(Kd, p->bott.Cin, p->c_b, p->t_b); fwd += f; dense += f; bwd += 2 * f; uniq_f += f; uniq_b += 2 * f; }
     for (int j = 0; j < L; ++j) {
         const double f = cf(Ku, p->ush[j].c_skip + p->ush[j].c_cur, p->ush[j].cout, p->ush[j].t_conv);
-        fwd += f; dense += f; bwd += 2 * f;
+        fwd += f; dense += f; bwd += 2 * f; uniq_f += f; uniq_b += 2 * f;
     }
-    { const double f = p->Sh * cf(Ko, C + F, C, p->Tout); fwd += f; dense += f; bwd += 2 * f; }
-    p->fwd_flops = fwd; p->bwd_flops = bwd; p->fwd_dense = dense;
+    { const double f = p->Sh * cf(Ko, C + F, C, p->Tout); fwd += f; dense += f; bwd += 2 * f; uniq_f += f; uniq_b += 2 * f; }
+    p->fwd_flops = fwd; p->bwd_flops = bwd; p->fwd_dense = dense; p->fwd_unique = uniq_f; p->bwd_unique = uniq_b;
 
     // ---- device-side descriptor table (the only device memory the plan owns) ----
     if (!p->wt.empty()) {
@@ -508,6 +533,8 @@ extern "C" int wun_plan_query(const wun_plan* p, wun_plan_info* info) {
     info->num_params = n; info->arena_floats = p->arena; info->workspace_floats = p->ws;
     info->num_tensors = (int64_t)p->tensors.size(); info->num_outputs = p->S;
     info->fwd_flops = p->fwd_flops; info->bwd_flops = p->bwd_flops; info->fwd_flops_dense = p->fwd_dense;
+    info->fwd_flops_unique = p->fwd_unique; info->bwd_flops_unique = p->bwd_unique;
+    info->compute_dtype_effective = p->bf16 ? 1 : 0;
     return WUN_OK;
 }
 
@@ -895,18 +922,36 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
             a.Tin = d.t_in; a.shift = 0; a.W = params + cl.woff; a.bias = params + cl.boff;
             a.KW = Kd; a.N = a.N0 = d.cout; a.Tout = d.t_dec; a.flags = F_LRELU;
             set_dst0(a, ws, p->dec[i], 0, nullptr);
+            if (p->dedup) {
+                // ... and, where 2q lies inside the crop window, into the skip window as well: the decimated stream IS a
+                // slice of the encoder output (:98-100), one value, one rounding
+                a.dec = ws + p->skip[i].off; a.decbs = p->skip[i].bs; a.decpitch = p->skip[i].pitch;
+                a.dec_exp = 1; a.dec_lo = d.cs; a.dec_len = (unsigned)d.tc;
+            }
             HIP_TRY(conv_dispatch(p, a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
-            // full-rate conv only over the window the skip connection crops (Utils.py:104-123);
+            // the rest of the window the skip connection crops (Utils.py:104-123) -- dedup plans: its ODD positions, a second
+            // stride-2 conv over x shifted by one sample, stored with stride 2; else a full-rate conv over the whole window;
             // independent of the decimating conv -> side stream, own half of the split-K scratch
             ConvArgs b = conv_base(p);
-            set_src0(b, ws, *x, d.cs, d.cin);
-            b.Tin = d.tc + Kd - 1; b.shift = 0; b.W = params + cl.woff; b.bias = params + cl.boff;
-            b.KW = Kd; b.N = b.N0 = d.cout; b.Tout = d.tc; b.flags = F_LRELU;
-            set_dst0(b, ws, p->skip[i], 0, nullptr);
+            bool have_b = true;
+            if (p->dedup) {
+                have_b = d.n_odd > 0;
+                set_src0(b, ws, *x, d.t_odd0, d.cin);
+                b.loader = LOADER_DEINT;
+                b.Tin = d.t_in - d.t_odd0; b.shift = 0; b.W = params + cl.woff; b.bias = params + cl.boff;
+                b.KW = Kd; b.N = b.N0 = d.cout; b.Tout = d.n_odd; b.flags = F_LRELU;
+                set_dst0(b, ws, p->skip[i], d.t_odd0 - d.cs, nullptr);
+                b.ostride = 2;
+            } else {
+                set_src0(b, ws, *x, d.cs, d.cin);
+                b.Tin = d.tc + Kd - 1; b.shift = 0; b.W = params + cl.woff; b.bias = params + cl.boff;
+                b.KW = Kd; b.N = b.N0 = d.cout; b.Tout = d.tc; b.flags = F_LRELU;
+                set_dst0(b, ws, p->skip[i], 0, nullptr);
+            }
             if (i < defer_below) {
                 deferred[(size_t)i] = b;
-                deferred_pos[(size_t)i] = (long long)p->ci++;       // its position in the canonical launch order
-            } else {
+                deferred_pos[(size_t)i] = have_b ? (long long)p->ci++ : -2;   // its position in the canonical launch order
+            } else if (have_b) {
                 HIP_TRY(conv_dispatch(p, b, ws + p->conv_part_off + part_half, part_q, s2));
                 side_used = side_used || (s2 != s);
             }
@@ -914,8 +959,9 @@ extern "C" int wun_forward(const wun_plan* p, const float* params, const float* 
                 // every input the deferred windows read has been issued on `s`: start them on the third stream
                 if ((rc0 = stream_dep(p, s, s3))) return rc0;
                 for (int k = defer_below - 1; k >= 0; --k) {
-                    HIP_TRY(conv_dispatch(p, deferred[(size_t)k], ws + p->conv_part_off + part_half + part_q, part_q, s3,
-                                          deferred_pos[(size_t)k]));
+                    if (deferred_pos[(size_t)k] != -2)
+                        HIP_TRY(conv_dispatch(p, deferred[(size_t)k], ws + p->conv_part_off + part_half + part_q, part_q, s3,
+                                              deferred_pos[(size_t)k]));
                     HIP_TRY(hipEventRecord(p->skip_ev[(size_t)k], s3));
                 }
             }
@@ -1172,17 +1218,14 @@ static int run_narrow_wgrad(const wun_plan* p, NarrowWgradArgs* parts, int npart
                             const long long* boff, float* ws, float* grads, hipStream_t main, hipStream_t s) {
     int rcd = WUN_OK;
     hipStream_t side_of_caller = s;                            // (bucket events of the data-parallel path are recorded there)
-    // bf16 mode: narrow_wgrad_kernel (the LDS-staged form: the output head, audio-input convs with < 4 taps) runs ALONE on the
-    // device -- on the caller's stream, after whatever the side streams still hold.  Measured (round 5, tools/repro_probe.py,
-    // DESIGN 5g(9)): with ragged rows (context: 16389 output positions) the head's kernel gradient came out different by
-    // 1e-5 .. 8e-4 of max|g| in 10 - 100 % of the steps of a process whenever bf16 MFMA kernels ran beside this kernel; every
-    // other tensor of the step stayed bit-identical, the exact-fp32 mode never showed it.  Traced to the kernel's packed fp32
-    // VALU instructions (identical LDS tiles, different accumulators; gone when the translation unit is built without them:
-    // csrc/Makefile, NO_PK_FP32 -- which is how the library is built now).  The placement is kept on top of that for this
-    // round: the head is the first launch of the backward pass that would leave the caller's stream, so it costs the dependent
-    // chain the kernel itself (~30 us per step, ~1 % of the bf16 step) and two idle joins.  WUN_BF16_HEAD_OVERLAP=1: the side
-    // stream again (0 of 24 differing steps with the packed instructions gone, 24 of 24 with them, same boxes).
-    if (p->bf16 && s != main && getenv("WUN_BF16_HEAD_OVERLAP") == nullptr) {
+    // bf16 mode, history (round 5): built WITH packed fp32 VALU instructions, narrow_wgrad_kernel (the LDS-staged
+    // form: the output head, audio-input convs with < 4 taps) returned different accumulators from run to run whenever bf16 MFMA
+    // kernels ran beside it; round 5 built the unit without them AND, as a second line, ran this launch alone on the caller's
+    // stream.  Round 6: tools/pk_fma_probe.hip reproduces the defect stand-alone (the compiler's packed instruction mix beside a
+    // v_mfma_f32_16x16x32_bf16 spinner: 2085 of 10000 launches differ; alone, beside an fp32-MFMA spinner, or built without
+    // packed ops: 0), the library with packed ops + overlap differs in 60 of 60 probe steps, the shipped build with overlap in
+    // 0 of 600 -- so the launch is back on the side stream (~1 % of the bf16 step).  WUN_BF16_HEAD_SERIAL=1: round 5's placement.
+    if (p->bf16 && s != main && getenv("WUN_BF16_HEAD_SERIAL") != nullptr) {
         bool lds_form = false;
         for (int i = 0; i < nparts; ++i) lds_form = lds_form || narrow_wgrad_uses_lds(parts[i]);
         if (lds_form) {
@@ -1293,7 +1336,25 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
         f.flags = F_PHASE2; f.C0 = d.cout; f.B = p->B;
         return (d.cin & 3) == 0 && f.Tout >= 256 && conv_natural_wgs_phase2(f) >= 256;
     };
-    auto level_early = [&](int i) { return early_win && i > 0 && !level_fused(i); };
+    // dedup plans: ranges of dz_dec[i - 1] that two more writers touch before / beside the row-wide transposed conv of level i --
+    // E = the even half of skip window i - 1's gradient (stored by up level L - i's input gradient), W = the input gradient of
+    // level i's odd window positions.  The early form of W (it ADDS inside E and stores elsewhere; the row-wide conv then adds
+    // inside W) needs E inside W, which the centred crops of every shipped config give; else W runs after the row-wide conv.
+    auto e_range = [&](int i, int& lo, int& len) { lo = p->dsh[i].t_ev0 / 2; len = p->dsh[i].n_even; };
+    auto w_range = [&](int i, int& lo, int& len) {
+        const DownShape& d = p->dsh[i];
+        if (p->dedup) { lo = d.t_odd0; len = d.n_odd > 0 ? 2 * (d.n_odd - 1) + Kd : 0; }
+        else { lo = d.cs; len = d.tc + Kd - 1; }
+    };
+    // WUN_EARLY_WINDOW=all: the odd-window input gradient of EVERY level leaves the dependent chain (experiment switch)
+    const bool early_all = ew_env != nullptr && ew_env[0] == 'a';
+    auto level_early = [&](int i) {
+        if (!(early_win && i > 0 && (early_all || !level_fused(i)))) return false;
+        if (!p->dedup) return true;
+        int elo, elen, wlo, wlen;
+        e_range(i - 1, elo, elen); w_range(i, wlo, wlen);
+        return wlen > 0 && (elen == 0 || (wlo <= elo && elo + elen <= wlo + wlen));
+    };
     if (early_win && p->win_ev.size() < (size_t)L) {
         p->win_ev.resize(L, nullptr);
         for (auto& e : p->win_ev)
@@ -1310,6 +1371,45 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
         a.N = a.N0 = d.cin; a.Tout = d.tc + Kd - 1;
         set_dst0(a, ws, p->dz_dec[i - 1], d.cs, &p->dec[i - 1]);
         return a;
+    };
+    // Transposed stride-2 conv of down level i into dz_dec[i - 1] (masked with dec[i - 1]'s LeakyReLU branch): of the decimated
+    // stream's gradient dz_dec[i] over the whole row (odd = false), or -- dedup plans -- of the odd window positions' gradient
+    // dz_odd[i] into [t_odd0, t_odd0 + 2 (n_odd - 1) + Kd) (odd = true).  Both output phases fused in one launch (a lane owns 8
+    // consecutive outputs) when the launch fills the chip, else one phase at a time (those launches can use split-K).
+    // accum: add to what the row holds inside [acc_lo, acc_lo + acc_len) (acc_len == 0: everywhere), store elsewhere.
+    auto tconv2 = [&](int i, bool odd, bool accum, int acc_lo, unsigned acc_len, hipStream_t st, float* part, long long cap) -> int {
+        const DownShape& d = p->dsh[i];
+        const ConvLayer& cl = p->down[i];
+        const Buf& src = odd ? p->dz_odd[i] : p->dz_dec[i];
+        const int n_in = odd ? d.n_odd : d.t_dec;
+        const int out_off = odd ? d.t_odd0 : 0;
+        const int out_len = odd ? 2 * (d.n_odd - 1) + Kd : d.t_in;
+        ConvArgs f = conv_base(p);
+        set_src0(f, ws, src, 0, d.cout);
+        f.Tin = n_in; f.KW = cl.J0; f.kw_full = Kd; f.shift = cl.J0 - 1; f.W = ws + cl.wt_ph2;
+        f.N = f.N0 = d.cin; f.Tout = (out_len + 1) / 2; f.Tlim = out_len; f.flags = F_PHASE2;
+        set_dst0(f, ws, p->dz_dec[i - 1], out_off, &p->dec[i - 1]);
+        if (accum) { f.flags |= F_ACCUM; f.acc_lo = acc_lo; f.acc_len = acc_len; }
+        // (bf16 mode: always fused when the channel count allows -- one launch, the gradient tile staged once,
+        //  contiguous 32-byte stores instead of two stride-2 scatter passes)
+        // (WUN_ODD_FUSE_MIN: workgroup floor of the fused form for the odd-window launches; experiment switch)
+        static const int odd_min = getenv("WUN_ODD_FUSE_MIN") ? atoi(getenv("WUN_ODD_FUSE_MIN")) : 256;
+        const int tmin = odd ? std::min(256, odd_min) : 256, wmin = odd ? odd_min : 256;
+        if ((d.cin & 3) == 0 && (p->bf16 || (f.Tout >= tmin && conv_natural_wgs_phase2(f) >= wmin))) {
+            HIP_TRY(conv_dispatch(p, f, part, cap, st));
+            return WUN_OK;
+        }
+        for (int ph = 0; ph < 2; ++ph) {
+            ConvArgs a = conv_base(p);
+            set_src0(a, ws, src, 0, d.cout);
+            a.Tin = n_in; a.KW = cl.Jp[ph]; a.shift = cl.Jp[ph] - 1; a.W = ws + cl.wt_ph[ph];
+            a.N = a.N0 = d.cin; a.Tout = (out_len - ph + 1) / 2;
+            set_dst0(a, ws, p->dz_dec[i - 1], out_off + ph, &p->dec[i - 1]);
+            a.ostride = 2;
+            if (accum) { a.flags |= F_ACCUM; a.acc_lo = acc_lo; a.acc_len = acc_len; }
+            if (a.Tout > 0) HIP_TRY(conv_dispatch(p, a, part, cap, st));
+        }
+        return WUN_OK;
     };
     auto flush_wgrads = [&]() -> int {
         if (pend.empty() && pend_win.empty()) return WUN_OK;
@@ -1329,7 +1429,14 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
             // own quarter of the split-K scratch per side stream (the chain on `s` uses the first half)
             hipStream_t sw = wstream();
             float* part = ws + p->conv_part_off + cpart_half + ((sw == s3 && s3 != s2) ? cpart_q : 0);
-            HIP_TRY(conv_dispatch(p, window_dgrad_args(i), sw == s ? ws + p->conv_part_off : part, sw == s ? cpart_half : cpart_q, sw));
+            if (p->dedup) {
+                int elo, elen;
+                e_range(i - 1, elo, elen);
+                int rcw = tconv2(i, true, elen > 0, elo, (unsigned)elen, sw, sw == s ? ws + p->conv_part_off : part, sw == s ? cpart_half : cpart_q);
+                if (rcw) return rcw;
+            } else {
+                HIP_TRY(conv_dispatch(p, window_dgrad_args(i), sw == s ? ws + p->conv_part_off : part, sw == s ? cpart_half : cpart_q, sw));
+            }
             if (sw != s) HIP_TRY(hipEventRecord(p->win_ev[(size_t)i], sw));
         }
         pend_win.clear();
@@ -1430,6 +1537,18 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
             a.N = u.c_skip + u.c_cur; a.N0 = u.c_skip; a.Tout = u.t_up;
             set_dst0(a, ws, p->dz_skip[i], 0, &p->skip[i]);
             set_dst1(a, ws, p->d_ups[j], 0, nullptr);
+            if (p->dedup) {
+                // window element q sits at absolute conv position cs + q: the even positions are elements of the decimated
+                // stream -- their gradient goes into dz_dec[i] (index (cs + q) / 2), the odd ones compact into dz_odd[i]
+                const DownShape& d = p->dsh[i];
+                float* ev = ws + p->dz_dec[i].off + d.t_ev0 / 2;
+                float* od = ws + p->dz_odd[i].off;
+                const bool cs_even = (d.cs & 1) == 0;
+                a.dec = cs_even ? ev : od;  a.decbs = cs_even ? p->dz_dec[i].bs : p->dz_odd[i].bs;
+                a.decpitch = cs_even ? p->dz_dec[i].pitch : p->dz_odd[i].pitch;
+                a.dec1 = cs_even ? od : ev; a.dec1bs = cs_even ? p->dz_odd[i].bs : p->dz_dec[i].bs;
+                a.dec1pitch = cs_even ? p->dz_odd[i].pitch : p->dz_dec[i].pitch;
+            }
             const Buf& prev = (j == 0) ? p->bott_out : p->upo[j - 1];
             const Buf& dzprev = (j == 0) ? p->dz_bott : p->dz_upo[j - 1];
             // linear interpolation: a launch that ends in the split-K epilogue kernel applies the adjoint of the 2x
@@ -1473,6 +1592,12 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
             a.ostride = 2; a.flags = F_ACCUM;
         } else {
             set_dst0(a, ws, p->dz_dec[L - 1], 0, &p->dec[L - 1]);
+            if (p->dedup && p->dsh[L - 1].n_even > 0) {
+                // (the even half of skip window L-1's gradient is already there)
+                int elo, elen;
+                e_range(L - 1, elo, elen);
+                a.flags = F_ACCUM; a.acc_lo = elo; a.acc_len = (unsigned)elen;
+            }
         }
         HIP_TRY(conv_dispatch(p, a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
     }
@@ -1499,10 +1624,16 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
             } else {
                 nw[0].Tin = d.t_in; nw[0].shift = 0; nw[0].stride = 2; nw[0].off0 = 0;
                 nw[0].dz = ws + p->dz_dec[0].off; nw[0].dzbs = p->dz_dec[0].bs; nw[0].dzpitch = p->dz_dec[0].pitch; nw[0].Tq = d.t_dec;
-                nw[1].Tin = d.tc + Kd - 1; nw[1].shift = 0; nw[1].stride = 1; nw[1].off0 = d.cs;
-                nw[1].dz = ws + p->dz_skip[0].off; nw[1].dzbs = p->dz_skip[0].bs; nw[1].dzpitch = p->dz_skip[0].pitch; nw[1].Tq = d.tc;
+                if (p->dedup) {
+                    nw[1].Tin = d.t_in - d.t_odd0; nw[1].shift = 0; nw[1].stride = 2; nw[1].off0 = d.t_odd0;
+                    nw[1].dz = ws + p->dz_odd[0].off; nw[1].dzbs = p->dz_odd[0].bs; nw[1].dzpitch = p->dz_odd[0].pitch; nw[1].Tq = d.n_odd;
+                } else {
+                    nw[1].Tin = d.tc + Kd - 1; nw[1].shift = 0; nw[1].stride = 1; nw[1].off0 = d.cs;
+                    nw[1].dz = ws + p->dz_skip[0].off; nw[1].dzbs = p->dz_skip[0].bs; nw[1].dzpitch = p->dz_skip[0].pitch; nw[1].Tq = d.tc;
+                }
             }
-            narrow = narrow_wgrad_supported(nw[0]) && (same || narrow_wgrad_supported(nw[1])) &&
+            const int nparts0 = same ? 1 : ((p->dedup && d.n_odd == 0) ? 1 : 2);
+            narrow = narrow_wgrad_supported(nw[0]) && (nparts0 == 1 || narrow_wgrad_supported(nw[1])) &&
                      (p->bf16 || (getenv("WUN_NO_NARROW") == nullptr && getenv("WUN_NO_NARROW_DOWN0") == nullptr));
             // (bf16 mode: the narrow kernels are the only ones that read fp32 audio against bf16 gradients)
             if (p->bf16 && !narrow) return fail(WUN_ERR_UNSUPPORTED, "bf16 mode: audio-input conv shape not served by the narrow weight-gradient kernels");
@@ -1510,7 +1641,7 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
         if (narrow) {
             if ((rc = flush_wgrads())) return rc;
             const long long woff[4] = {cl.woff, 0, 0, 0}, boff[4] = {cl.boff, 0, 0, 0};
-            if ((rc = run_narrow_wgrad(p, nw, same ? 1 : 2, woff, boff, ws, grads, s, wstream()))) return rc;
+            if ((rc = run_narrow_wgrad(p, nw, (same || (p->dedup && d.n_odd == 0)) ? 1 : 2, woff, boff, ws, grads, s, wstream()))) return rc;
             if ((rc = ready2(cl.woff))) return rc;
         } else if (same) {
             WgradArgs w = wgrad_base(p);
@@ -1534,48 +1665,43 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
             w[0].loader = LOADER_DEINT; w[0].Tin = d.t_in; w[0].shift = 0; w[0].KW = Kd;
             wset_dz(w[0], ws + p->dz_dec[i].off, p->dz_dec[i].bs, p->dz_dec[i].pitch, d.cout, d.t_dec);
             w[1] = wgrad_base(p);
-            wset_src0(w[1], ws, x, d.cs, d.cin);
-            w[1].Tin = d.tc + Kd - 1; w[1].shift = 0; w[1].KW = Kd;
-            wset_dz(w[1], ws + p->dz_skip[i].off, p->dz_skip[i].bs, p->dz_skip[i].pitch, d.cout, d.tc);
-            if ((rc = submit_wgrad(w, 2, cl))) return rc;
+            int nparts = 2;
+            if (p->dedup) {
+                // the odd window positions: the same stride-2 geometry over x shifted by t_odd0 samples
+                nparts = d.n_odd > 0 ? 2 : 1;
+                wset_src0(w[1], ws, x, d.t_odd0, d.cin);
+                w[1].loader = LOADER_DEINT; w[1].Tin = d.t_in - d.t_odd0; w[1].shift = 0; w[1].KW = Kd;
+                wset_dz(w[1], ws + p->dz_odd[i].off, p->dz_odd[i].bs, p->dz_odd[i].pitch, d.cout, d.n_odd);
+            } else {
+                wset_src0(w[1], ws, x, d.cs, d.cin);
+                w[1].Tin = d.tc + Kd - 1; w[1].shift = 0; w[1].KW = Kd;
+                wset_dz(w[1], ws + p->dz_skip[i].off, p->dz_skip[i].bs, p->dz_skip[i].pitch, d.cout, d.tc);
+            }
+            if ((rc = submit_wgrad(w, nparts, cl))) return rc;
             if (i > 0) {
-                // transposed stride-2 conv: both output phases fused in one launch (a lane owns 8
-                // consecutive outputs) when the launch fills the chip, else one phase at a time
-                // (those launches can use split-K)
-                ConvArgs f = conv_base(p);
-                set_src0(f, ws, p->dz_dec[i], 0, d.cout);
-                f.Tin = d.t_dec; f.KW = cl.J0; f.kw_full = Kd; f.shift = cl.J0 - 1; f.W = ws + cl.wt_ph2;
-                f.N = f.N0 = d.cin; f.Tout = (d.t_in + 1) / 2; f.Tlim = d.t_in; f.flags = F_PHASE2;
-                set_dst0(f, ws, p->dz_dec[i - 1], 0, &p->dec[i - 1]);
                 const bool win_early = level_early(i) && !p->win_ev.empty();
+                int alo = 0, alen = 0;
+                bool acc = false;
                 if (win_early) {
                     // the window part is already in dz_dec[i-1] (side stream): wait for it, add inside the window (a
                     // launch still sitting in the queue -- win_ev[i] would be last step's record -- is issued now)
                     if (std::find(pend_win.begin(), pend_win.end(), i) != pend_win.end() && (rc = flush_wgrads())) return rc;
                     if (s2 != s) HIP_TRY(hipStreamWaitEvent(s, p->win_ev[(size_t)i], 0));
-                    f.flags |= F_ACCUM; f.acc_lo = d.cs; f.acc_len = (unsigned)(d.tc + Kd - 1);
+                    w_range(i, alo, alen);
+                    acc = true;
+                } else if (p->dedup) {
+                    e_range(i - 1, alo, alen);        // the even half of skip window i-1's gradient is already there
+                    acc = alen > 0;
                 }
-                // (bf16 mode: always fused when the channel count allows -- one launch, the gradient tile staged once,
-                //  contiguous 32-byte stores instead of two stride-2 scatter passes)
-                if ((d.cin & 3) == 0 && (p->bf16 ||
-                                         (f.Tout >= 256 && conv_natural_wgs_phase2(f) >= 256))) {
-                    HIP_TRY(conv_dispatch(p, f, ws + p->conv_part_off, p->conv_part_floats / 2, s));
-                } else {
-                    for (int ph = 0; ph < 2; ++ph) {
-                        ConvArgs a = conv_base(p);
-                        set_src0(a, ws, p->dz_dec[i], 0, d.cout);
-                        a.Tin = d.t_dec; a.KW = cl.Jp[ph]; a.shift = cl.Jp[ph] - 1; a.W = ws + cl.wt_ph[ph];
-                        a.N = a.N0 = d.cin; a.Tout = (d.t_in - ph + 1) / 2;
-                        set_dst0(a, ws, p->dz_dec[i - 1], ph, &p->dec[i - 1]);
-                        a.ostride = 2;
-                        if (win_early) { a.flags |= F_ACCUM; a.acc_lo = d.cs; a.acc_len = (unsigned)(d.tc + Kd - 1); }
+                if ((rc = tconv2(i, false, acc, alo, (unsigned)alen, s, ws + p->conv_part_off, p->conv_part_floats / 2))) return rc;
+                if (!win_early) {
+                    if (p->dedup) {
+                        if (d.n_odd > 0 && (rc = tconv2(i, true, true, 0, 0u, s, ws + p->conv_part_off, p->conv_part_floats / 2))) return rc;
+                    } else {
+                        ConvArgs a = window_dgrad_args(i);
+                        a.flags = F_ACCUM;
                         HIP_TRY(conv_dispatch(p, a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
                     }
-                }
-                if (!win_early) {
-                    ConvArgs a = window_dgrad_args(i);
-                    a.flags = F_ACCUM;
-                    HIP_TRY(conv_dispatch(p, a, ws + p->conv_part_off, p->conv_part_floats / 2, s));
                 }
             }
         }
@@ -1608,7 +1734,7 @@ extern "C" int wun_plan_tune(const wun_plan* p, const float* params, const float
 // Tuning-table header: identifies the plan (every config key that changes a launch), the launch
 // order of this library build and the number of entries per section, so a table written for
 // another plan, another library build or truncated on disk is rejected at import.
-#define WUN_TUNE_ORDER "r4a"      /* bump whenever the order / number of conv or wgrad launches changes */
+#define WUN_TUNE_ORDER "r6a"      /* bump whenever the order / number of conv or wgrad launches changes */
 #define WUN_TUNE_ORDER_BF16 "r5b" /* ... of the bf16 mode (round 5: bf16 activations in HBM, other tile menu limits) */
 static std::string tune_header(const wun_plan* p, size_t ncf, size_t ncb, size_t nwg) {
     char line[320];
@@ -1623,7 +1749,9 @@ static std::string tune_header(const wun_plan* p, size_t ncf, size_t ncb, size_t
     // a non-default early-window mode changes the order of the backward conv launches: such tables only match themselves
     if (const char* ew = getenv("WUN_EARLY_WINDOW")) {
         if (ew[0] == '0') h += " ew=0";
+        if (ew[0] == 'a') h += " ew=all";
     }
+    if (const char* of = getenv("WUN_ODD_FUSE_MIN")) h += std::string(" oddfuse=") + of;
     return h;
 }
 
@@ -1713,6 +1841,8 @@ static int g_op_wg_mtw = 0, g_op_wg_nw = 0, g_op_wg_nsplit = 0;   // wun_op_forc
 static int g_op_wg_bf16 = 0;                                       // wun_op_set_wgrad_bf16 (test hook)
 static int g_op_wg_narrow = 0;                                     // wun_op_set_wgrad_narrow (test hook)
 static int g_op_wg_win = 0;                                        // wun_op_set_wgrad_win (test hook)
+static float* g_op_copy0 = nullptr; static float* g_op_copy1 = nullptr;   // wun_op_set_conv_copies (test hook)
+static int g_op_copy_t0 = 0, g_op_copy_t1 = 0, g_op_copy_exp = 0, g_op_copy_lo = 0, g_op_copy_len = 0, g_op_acc_lo = 0, g_op_acc_len = 0;
 static float* op_scratch() {
     static float* buf = nullptr;
     if (!buf && hipMalloc((void**)&buf, kOpScratchFloats * sizeof(float)) != hipSuccess) {
@@ -1972,7 +2102,21 @@ extern "C" int wun_op_conv1d_ex(const float* x0, int c0, const float* x1, int c1
     a.Tin = t_in; a.shift = pad_left; a.W = w; a.bias = bias; a.KW = k; a.N = a.N0 = cout; a.Tout = t_out;
     a.flags = (lrelu ? F_LRELU : 0) | (accumulate ? F_ACCUM : 0);
     a.dst0 = y; a.obs0 = (long long)cout * t_y; a.opitch0 = t_y; a.ooff0 = ooff; a.msk0 = mask;
+    if (g_op_copy0 != nullptr) {
+        a.dec = g_op_copy0; a.decpitch = g_op_copy_t0; a.decbs = (long long)cout * g_op_copy_t0;
+        a.dec_exp = g_op_copy_exp; a.dec_lo = g_op_copy_lo; a.dec_len = (unsigned)g_op_copy_len;
+    }
+    if (g_op_copy1 != nullptr) { a.dec1 = g_op_copy1; a.dec1pitch = g_op_copy_t1; a.dec1bs = (long long)cout * g_op_copy_t1; }
+    if (accumulate && g_op_acc_len > 0) { a.acc_lo = g_op_acc_lo; a.acc_len = (unsigned)g_op_acc_len; }
     HIP_TRY(op_launch_conv(a, (hipStream_t)stream));
+    return WUN_OK;
+}
+
+extern "C" int wun_op_set_conv_copies(float* copy0, int t0, int expand, int exp_lo, int exp_len, float* copy1, int t1,
+                                      int acc_lo, int acc_len) {
+    if ((copy0 && t0 < 1) || (copy1 && t1 < 1) || exp_len < 0 || acc_len < 0) return fail(WUN_ERR_INVALID, "bad copy geometry");
+    g_op_copy0 = copy0; g_op_copy_t0 = t0; g_op_copy_exp = expand ? 1 : 0; g_op_copy_lo = exp_lo; g_op_copy_len = exp_len;
+    g_op_copy1 = copy1; g_op_copy_t1 = t1; g_op_acc_lo = acc_lo; g_op_acc_len = acc_len;
     return WUN_OK;
 }
 

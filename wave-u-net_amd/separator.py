@@ -52,6 +52,12 @@ class _Plan(object):
             _lib.LOW_PRIORITY_PLANS["created"] += 1
         self.info = _lib.WunPlanInfo()
         _lib.check(lib.wun_plan_query(self.handle, C.byref(self.info)))
+        if int(self.info.compute_dtype_effective) != int(wcfg.compute_dtype):
+            # (num_initial_filters % 8 != 0, a tap-less conv phase, rows beyond the bf16 kernels' offsets: include/wun.h)
+            import warnings
+            warnings.warn("wun: compute_dtype='bf16' was requested but this configuration does not qualify for the bf16 "
+                          "mode -- the plan runs the exact-fp32 kernels (wun_plan_info.compute_dtype_effective = 0)",
+                          RuntimeWarning, stacklevel=3)
         self.tensors = []
         for i in range(self.info.num_tensors):
             ti = _lib.WunTensorInfo()
@@ -307,3 +313,12 @@ class UnetAudioSeparator(object):
 
     def plan_info(self):
         return self._active.info if self._active is not None else None
+
+    @property
+    def effective_dtype(self):
+        """'f32' or 'bf16': the arithmetic the active plan really runs (wun_plan_info.compute_dtype_effective) -- a config
+        that asks for the bf16 mode without qualifying for it gets the exact-fp32 plan."""
+        info = self.plan_info()
+        if info is None:
+            return None
+        return "bf16" if int(info.compute_dtype_effective) == 1 else "f32"
