@@ -71,8 +71,12 @@ typedef struct wun_config {
                                 /*     (rounded once, by the epilogue that writes it), convs / input gradients / weight  */
                                 /*     gradients on v_mfma_f32_16x16x32_bf16 with fp32 accumulate; parameters, weight    */
                                 /*     gradients, Adam state, the audio and the head's d(pre-activation) stay fp32.      */
-                                /*     Needs num_initial_filters % 8 == 0 (else the plan is the exact-fp32 plan;        */
-                                /*     wun_plan_activation reports the element size).                                   */
+                                /*     Needs num_initial_filters % 8 == 0 (else the plan is the exact-fp32 plan:        */
+                                /*     wun_plan_info.compute_dtype_effective says which one was built).                  */
+                                /*     Not recommended with upsampling = 1 (learned): the gradient of an interpolation    */
+                                /*     weight is a sum of DIFFERENCES of adjacent activations that are already rounded   */
+                                /*     to bf16 (cancellation amplifies the storage rounding: up to 0.5 of max|g| on the  */
+                                /*     312-element interp_0 of M5 against the un-rounded oracle, tests/test_gpu_bf16.py). */
     int32_t exclusive_streams;  /* scheduling hint, no effect on results.  1 = nothing else runs on this device  */
                                 /* beside the plan's calls: its side streams get the LOWEST queue priority (they  */
                                 /* fill the gaps of the dependent chain on the caller's stream, ~1 % per step).   */
@@ -180,7 +184,17 @@ int wun_loss_backward(const wun_plan* plan, const float* params, const float* mi
  * END of the arena towards 0, i.e. in backward completion order).  bucket_events[k] (hipEvent_t,
  * created by the caller) is recorded -- on an internal stream -- as soon as every gradient at an
  * offset >= bucket_starts[k] is final, so the caller can start that bucket's all-reduce on a
- * communication stream (hipStreamWaitEvent) while the rest of the backward pass still runs. */
+ * communication stream (hipStreamWaitEvent) while the rest of the backward pass still runs.
+ *
+ * A C caller (no torch.distributed) pairs the events with its own RCCL calls -- the library itself links no collective
+ * library -- exactly as wave-u-net_amd/parallel.py does:
+ *     hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) for every bucket;  comm = a non-blocking stream, highest priority
+ *     wun_loss_backward_ex(..., stream, starts, (void* const*)ev, n);
+ *     for k in 0..n-1:  hipStreamWaitEvent(comm, ev[k], 0);
+ *                       ncclAllReduce(grads + starts[k], grads + starts[k], end[k] - starts[k], ncclFloat, ncclSum, nccl_comm, comm);
+ *     hipEventRecord(done, comm); hipStreamWaitEvent(stream, done, 0);
+ *     wun_adam_step(..., grad_scale = 1.0f / world_size, stream);
+ * with wun_config.exclusive_streams = 0 (low-priority side streams beside a communication stream cost 40 %). */
 int wun_loss_backward_ex(const wun_plan* plan, const float* params, const float* mix_btc,
                          float* workspace, const float* outputs, const float* targets,
                          float* grads, float* loss, void* stream,

@@ -885,7 +885,7 @@ def test_benchmarked_configuration_b16_tuned_vs_oracle(lib):
     # error per conv kernel is recorded and bounded too (1.0e-4 .. 1.3e-4 observed; a wrong tap / dropped position /
     # missing split moves it by 1e-2 .. 1).  What shows that the kernels themselves are exact is the B = 2 test above,
     # where no pre-activation is borderline: 6e-7.
-    _grad_check(sep, tp, ograds, tol=GRAD_TOL_FULL_TUNED, tag="bench_config_B16_tuned")
+    e_free = _grad_check(sep, tp, ograds, tol=GRAD_TOL_FULL_TUNED, tag="bench_config_B16_tuned")
     l2, which = _grad_rel_l2(sep, tp, ograds)
     record("gradients_rel_l2_vs_float64_oracle", "bench_config_B16_tuned (worst: %s)" % which, l2, GRAD_L2_TOL)
     assert l2 <= GRAD_L2_TOL, (l2, which)
@@ -903,6 +903,12 @@ def test_benchmarked_configuration_b16_tuned_vs_oracle(lib):
     l2p, whichp = _grad_rel_l2(sep, tp, pgrads)
     record("gradients_rel_l2_vs_float64_oracle", "bench_config_B16_tuned (branch-pinned; worst: %s)" % whichp, l2p, GRAD_TOL_PINNED)
     assert l2p <= GRAD_TOL_PINNED and e_pin <= GRAD_TOL_PINNED, (e_pin, l2p, whichp)
+    # The free comparison's bound follows from the flip count: with NO flipped branch the free oracle
+    # IS the pinned one and must meet the pinned bound; every flipped branch may move the gradients upstream of it by a few
+    # 1e-4 of max|g| (one x5 in one dz element: profiles/round4_wsdiff_single_mask_flip.txt), up to SURVEY section 7's 1e-3.
+    tol_free = min(GRAD_TOL_FULL_TUNED, GRAD_TOL_PINNED + 2.5e-4 * flips[0])
+    record("gradients_vs_float64_oracle", "bench_config_B16_tuned (free oracle; bound from %d flipped branches)" % flips[0], e_free, tol_free)
+    assert e_free <= tol_free, (e_free, tol_free, flips)
     # ... and the same table with its forward entries reset (heuristic forward kernels, tuned backward kernels): other
     # masks, same bounds
     if text is not None and tr.tune_source == "pinned":

@@ -61,6 +61,16 @@ __global__ __launch_bounds__(256) void probe_a(const float* src, unsigned* out, 
                 asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc0) : "v"(xlo), "v"(zlo));
                 asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc1) : "v"(xhi), "v"(zhi));
                 asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(bs) : "v"(zlo));
+            } else if (PK == 5) {
+                // ONLY op_sel_hi:[1,0,1] (the HIGH lane reads the LOW half of src1)
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc0) : "v"(xlo), "v"(zlo));
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc1) : "v"(xhi), "v"(zhi));
+                asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(bs) : "v"(zlo));
+            } else if (PK == 6) {
+                // ONLY op_sel:[0,1,0] (the LOW lane reads the HIGH half of src1)
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc0) : "v"(xlo), "v"(zlo));
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc1) : "v"(xhi), "v"(zhi));
+                asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(bs) : "v"(zlo));
             } else if (PK == 3) {
                 // v_pk_mov_b32 assembling an operand pair from halves of two pairs, consumed by the next packed FMA
                 f32x2 t;
@@ -217,16 +227,17 @@ int main(int argc, char** argv) {
     CHECK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CHECK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
     // spinner length: ~ 2 ms per launch, so a handful are always queued beside A
     const int spin_iters = 60000;
-    std::vector<unsigned> ref[5], got((size_t)RING * NWG * 2);
+    std::vector<unsigned> ref[7], got((size_t)RING * NWG * 2);
     const char* arm_name[3] = {"A alone", "A beside the bf16-MFMA spinner (v_mfma_f32_16x16x32_bf16)", "A beside the fp32-MFMA spinner (v_mfma_f32_16x16x4_f32)"};
 #ifdef NOPK_BUILD
-    const char* kind_name[6] = {"asm: plain v_pk_fma/mul/add     ", "asm: scalar VALU                ", "narrow loop, built WITHOUT pk ops",
+    const char* kind_name[8] = {"asm: plain v_pk_fma/mul/add     ", "asm: scalar VALU                ", "narrow loop, built WITHOUT pk ops",
 #else
-    const char* kind_name[6] = {"asm: plain v_pk_fma/mul/add     ", "asm: scalar VALU                ", "narrow loop, compiler's pk ops   ",
+    const char* kind_name[8] = {"asm: plain v_pk_fma/mul/add     ", "asm: scalar VALU                ", "narrow loop, compiler's pk ops   ",
 #endif
-                                "asm: v_pk_fma with op_sel forms ", "asm: v_pk_mov_b32 -> v_pk_fma    ", "asm: v_mov half -> v_pk_fma      "};
+                                "asm: v_pk_fma with op_sel forms ", "asm: v_pk_mov_b32 -> v_pk_fma    ", "asm: v_mov half -> v_pk_fma      ",
+                                "asm: only op_sel_hi:[1,0,1]     ", "asm: only op_sel:[0,1,0]        "};
     for (int arm = 0; arm < 3; ++arm) {
-        for (int kind = 0; kind < 6; ++kind) {
+        for (int kind = 0; kind < 8; ++kind) {
 #ifdef NOPK_BUILD
             if (kind != 1 && kind != 2) continue;          // (the assembler of this build refuses the packed instructions)
 #endif
@@ -251,7 +262,9 @@ int main(int argc, char** argv) {
                     else if (kind == 2) hipLaunchKernelGGL(probe_n, dim3(NWG), dim3(256), 0, sa, src, out, i, iters_a * 4);
                     else if (kind == 3) hipLaunchKernelGGL(probe_a<2>, dim3(NWG), dim3(256), 0, sa, src, out, i, iters_a);
                     else if (kind == 4) hipLaunchKernelGGL(probe_a<3>, dim3(NWG), dim3(256), 0, sa, src, out, i, iters_a);
-                    else hipLaunchKernelGGL(probe_a<4>, dim3(NWG), dim3(256), 0, sa, src, out, i, iters_a);
+                    else if (kind == 5) hipLaunchKernelGGL(probe_a<4>, dim3(NWG), dim3(256), 0, sa, src, out, i, iters_a);
+                    else if (kind == 6) hipLaunchKernelGGL(probe_a<5>, dim3(NWG), dim3(256), 0, sa, src, out, i, iters_a);
+                    else hipLaunchKernelGGL(probe_a<6>, dim3(NWG), dim3(256), 0, sa, src, out, i, iters_a);
                 }
                 CHECK(hipEventRecord(e1, sa));
                 CHECK(hipStreamSynchronize(sa));

@@ -198,14 +198,46 @@ static Buf make_buf(long long& cur, int B, int C, int T, const char* name = null
 // elementwise / head / audio-input kernels) reads them: channel counts in whole groups of 8 (num_initial_filters % 8 == 0;
 // every shipped config: 24, the deep variant 48), no tap-less conv phase (a 1-tap filter with context), rows and tensors
 // inside the kernels' 32-bit offsets.  A plan that does not qualify is the exact-fp32 plan (wun_plan_query reports it).
-static bool bf16_plan_ok(const wun_config* c, int B, const std::vector<DownShape>& dsh, int t_b) {
+static bool bf16_plan_ok(const wun_config* c, int B, const std::vector<DownShape>& dsh, int t_b,
+                         const std::vector<UpShape>& ush, int c_b, int Sh) {
     if ((c->num_initial_filters & 7) != 0) return false;
     if (c->context && (c->filter_size < 2)) return false;
-    if (c->filter_size > 15 || c->merge_filter_size > 15) return false;
-    (void)B; (void)t_b;
-    for (const DownShape& d : dsh) {
-        if ((long long)d.t_in + 64 >= (1 << 23)) return false;                                 // 23-bit row elements
-        if ((long long)d.cout * ((d.t_conv + 15) & ~7) * 2 >= (1ll << 31)) return false;        // 32-bit byte offsets per excerpt
+    if (c->filter_size > 15 || c->merge_filter_size > 15 || c->output_filter_size > 15) return false;
+    (void)B;
+    // a row of `t` elements (+ halo) inside the kernels' 23-bit row elements, an excerpt's tensor inside 32-bit byte offsets
+    auto fits = [](long long ch, long long t) { return t + 64 < (1ll << 23) && ch * ((t + 15) & ~7ll) * 2 < (1ll << 31); };
+    for (const DownShape& d : dsh)
+        if (!fits(d.cout, d.t_conv) || !fits(d.cin, d.t_in)) return false;
+    if (!fits(c_b, t_b)) return false;
+    // up path (these were only checked at launch): the two sources of an up conv -- skip window and upsampled
+    // tensor, twice the channels of the down level at the same length --, its output and the gradient tensors of the same shapes
+    for (const UpShape& u : ush) {
+        if (!fits(u.c_skip, u.t_up) || !fits(u.c_cur, u.t_up) || !fits(u.cout, u.t_conv)) return false;
+        if ((u.c_skip & 7) != 0) return false;                  // an 8-channel group must not straddle the two sources
+    }
+    // output head: the narrow weight-gradient kernels (all sources in one launch, or one launch per source), or -- even
+    // channel counts -- the bf16 MFMA weight gradient on bf16 copies of the audio and the head's d(pre-activation)
+    if (Sh > 0) {
+        const int C = c->num_channels, F = c->num_initial_filters;
+        NarrowWgradArgs t;
+        memset(&t, 0, sizeof(t));
+        t.C0 = C; t.C1 = F; t.KW = c->output_filter_size; t.stride = 1; t.N = Sh * C; t.Nper = C;
+        bool ok = narrow_wgrad_supported(t);
+        if (!ok && (C & 1) == 0) {
+            WgradArgs w;
+            memset(&w, 0, sizeof(w));
+            w.C0 = C; w.C1 = F; w.KW = c->output_filter_size; w.N = C;
+            ok = wgrad_bf16_supported(w);
+        }
+        if (!ok) { t.N = t.Nper = C; ok = narrow_wgrad_supported(t); }
+        if (!ok) return false;
+    }
+    // audio-input conv: the narrow kernels read fp32 audio against bf16 gradients
+    {
+        NarrowWgradArgs t;
+        memset(&t, 0, sizeof(t));
+        t.C0 = c->num_channels; t.KW = c->filter_size; t.stride = c->context ? 2 : 1; t.N = t.Nper = dsh.empty() ? 0 : dsh[0].cout;
+        if (!narrow_wgrad_supported(t)) return false;
     }
     return true;
 }
@@ -327,7 +359,7 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
     const int B = p->B;
     // bf16 mode: every activation and activation-gradient tensor is born bf16 (the audio itself, the head's
     // d(pre-activation), weights, weight gradients and all scratch stay fp32)
-    p->bf16 = cfg->compute_dtype == 1 && bf16_plan_ok(cfg, B, p->dsh, p->t_b);
+    p->bf16 = cfg->compute_dtype == 1 && bf16_plan_ok(cfg, B, p->dsh, p->t_b, p->ush, p->c_b, p->Sh);
     const int eb = p->bf16 ? 2 : 4;
     p->dedup = !same && !p->bf16 && getenv("WUN_NO_DEDUP") == nullptr;
     p->mix_ncw = make_buf(w, B, C, p->Tin, "mix_ncw");
@@ -1346,8 +1378,13 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
         if (p->dedup) { lo = d.t_odd0; len = d.n_odd > 0 ? 2 * (d.n_odd - 1) + Kd : 0; }
         else { lo = d.cs; len = d.tc + Kd - 1; }
     };
-    // WUN_EARLY_WINDOW=all: the odd-window input gradient of EVERY level leaves the dependent chain (experiment switch)
-    const bool early_all = ew_env != nullptr && ew_env[0] == 'a';
+    // Which levels' window input gradients leave the dependent chain.  Dedup plans (round 6): ALL of them -- the odd-window
+    // launches are half the size of the old window convs, and for the middle levels (row-wide part fused, window part too
+    // small to fuse) the chain otherwise carries two phase launches + their split-K epilogues per level: same-box A/B, each arm
+    // autotuned, 8.14 -> 8.03 ms per step, 7.94 together with the lower fuse floor below (profiles/round6_ab_dedup_schedule.txt).
+    // Rounds 3 - 5 (full-window convs): only the deep levels, moving the FLOP-heavy ones changed nothing (8.98 vs 8.99).
+    // WUN_EARLY_WINDOW=deep | all | 0 overrides (a non-default mode is part of the tuning-table header).
+    const bool early_all = ew_env != nullptr ? ew_env[0] == 'a' : p->dedup;
     auto level_early = [&](int i) {
         if (!(early_win && i > 0 && (early_all || !level_fused(i)))) return false;
         if (!p->dedup) return true;
@@ -1392,8 +1429,9 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
         if (accum) { f.flags |= F_ACCUM; f.acc_lo = acc_lo; f.acc_len = acc_len; }
         // (bf16 mode: always fused when the channel count allows -- one launch, the gradient tile staged once,
         //  contiguous 32-byte stores instead of two stride-2 scatter passes)
-        // (WUN_ODD_FUSE_MIN: workgroup floor of the fused form for the odd-window launches; experiment switch)
-        static const int odd_min = getenv("WUN_ODD_FUSE_MIN") ? atoi(getenv("WUN_ODD_FUSE_MIN")) : 256;
+        // (the odd-window launches fuse from 64 workgroups / 64 output pairs on: they run on the side streams, where one
+        //  launch beats two phase launches + two split-K epilogues; WUN_ODD_FUSE_MIN overrides the floor)
+        static const int odd_min = getenv("WUN_ODD_FUSE_MIN") ? atoi(getenv("WUN_ODD_FUSE_MIN")) : 64;
         const int tmin = odd ? std::min(256, odd_min) : 256, wmin = odd ? odd_min : 256;
         if ((d.cin & 3) == 0 && (p->bf16 || (f.Tout >= tmin && conv_natural_wgs_phase2(f) >= wmin))) {
             HIP_TRY(conv_dispatch(p, f, part, cap, st));
@@ -1749,9 +1787,11 @@ static std::string tune_header(const wun_plan* p, size_t ncf, size_t ncb, size_t
     // a non-default early-window mode changes the order of the backward conv launches: such tables only match themselves
     if (const char* ew = getenv("WUN_EARLY_WINDOW")) {
         if (ew[0] == '0') h += " ew=0";
-        if (ew[0] == 'a') h += " ew=all";
+        if (ew[0] == 'a' && !p->dedup) h += " ew=all";
+        if (ew[0] == 'd' && p->dedup) h += " ew=deep";
     }
     if (const char* of = getenv("WUN_ODD_FUSE_MIN")) h += std::string(" oddfuse=") + of;
+    if (!p->same && !p->bf16 && !p->dedup) h += " dedup=0";       // (WUN_NO_DEDUP=1: rounds 1 - 5's launch sequence)
     return h;
 }
 
