@@ -1,5 +1,5 @@
 #!/bin/bash
-# FETCH_SIZE (KiB) of one operator launch under a given library build: tools/fetch_probe.sh <lib.so> <op_bench args...>
+# FETCH_SIZE (KiB) of one operator launch under a given library build: tools/probes/fetch_probe.sh <lib.so> <op_bench args...>
 lib=$1; shift
 R=$PWD
 cd /tmp && export TMPDIR=/tmp

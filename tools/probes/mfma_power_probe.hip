@@ -2,7 +2,7 @@
 // One wave per SIMD (256-thread blocks, 1 per CU) or two; operands stream from LDS (16-byte reads, one per 4 k-steps and
 // tile), 18 accumulator tiles (the 6 x 3 register tile of the weight-gradient kernel); LDS holds zeros, a constant or
 // random floats.  Reports TFLOP/s, shader cycles (s_memtime) per MFMA and s_memtime ticks per 100 MHz tick.
-// hipcc --offload-arch=gfx950 -O3 tools/mfma_power_probe.hip -o /tmp/mfma_power_probe && /tmp/mfma_power_probe
+// hipcc --offload-arch=gfx950 -O3 tools/probes/mfma_power_probe.hip -o /tmp/mfma_power_probe && /tmp/mfma_power_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

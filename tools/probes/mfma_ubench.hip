@@ -1,5 +1,5 @@
 // Micro-benchmark: issue rate of the exact-fp32 MFMA shapes on gfx950.
-// hipcc --offload-arch=gfx950 -O3 tools/mfma_ubench.hip -o tools/mfma_ubench && ./tools/mfma_ubench
+// hipcc --offload-arch=gfx950 -O3 tools/probes/mfma_ubench.hip -o tools/probes/mfma_ubench && ./tools/probes/mfma_ubench
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -14,7 +14,7 @@
 // checksums compared with the first launch's.  Reports launches / workgroups that differ.
 //   kernel N      : the library kernel's own inner loop (C++, see below) -- the compiler's packed instruction mix, or, built with
 //                   -DNOPK_BUILD -Xclang -target-feature -Xclang -packed-fp32-ops, what the library ships now.
-// build + run (GPU box): hipcc -O3 --offload-arch=gfx950 tools/pk_fma_probe.hip -o /tmp/pk_fma_probe && /tmp/pk_fma_probe [N]
+// build + run (GPU box): hipcc -O3 --offload-arch=gfx950 tools/probes/pk_fma_probe.hip -o /tmp/pk_fma_probe && /tmp/pk_fma_probe [N]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

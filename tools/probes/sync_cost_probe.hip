@@ -2,7 +2,7 @@
 // with after each kernel (a) nothing, (b) hipEventRecord (+ hipStreamWaitEvent on stream B), (c) hipStreamWriteValue32
 // (+ hipStreamWaitValue32 on B), (d) a 1-thread flag kernel (+ hipStreamWaitValue32 on B), (e) round 4: the event attached to
 // the kernel dispatch itself (hipExtLaunchKernelGGL's stopEvent: no packet of its own) (+ hipStreamWaitEvent on B).
-// build: hipcc -O3 --offload-arch=gfx950 tools/sync_cost_probe.hip -o /tmp/sync_probe
+// build: hipcc -O3 --offload-arch=gfx950 tools/probes/sync_cost_probe.hip -o /tmp/sync_probe
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <cstdio>

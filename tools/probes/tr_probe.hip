@@ -1,5 +1,5 @@
 // Probe of ds_read_b64_tr_b16 (gfx950): which LDS elements land in which lane.
-// build: hipcc -O3 --offload-arch=gfx950 tools/tr_probe.hip -o /tmp/tr_probe ; run on the GPU box.
+// build: hipcc -O3 --offload-arch=gfx950 tools/probes/tr_probe.hip -o /tmp/tr_probe ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef short s16x4 __attribute__((ext_vector_type(4)));

@@ -3,7 +3,7 @@
 //  with two transposing reads per fragment would need one element offset per TAP, i.e. arbitrary 2-byte alignment.)
 // For element offset `off` 0..7: lane i of a 16-lane group reads row (i >> 2) at columns off + 4*(i & 3) .. +3 of a
 // [64 rows][pitch] b16 image; expected: lane c receives column off + c of rows 4g .. 4g+3.  Also times 4096 dependent reads.
-// build: hipcc -O3 --offload-arch=gfx950 tools/tr_unaligned_probe.hip -o /tmp/tr_unaligned_probe ; run on the GPU box.
+// build: hipcc -O3 --offload-arch=gfx950 tools/probes/tr_unaligned_probe.hip -o /tmp/tr_unaligned_probe ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef short s16x4 __attribute__((ext_vector_type(4)));

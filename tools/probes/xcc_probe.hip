@@ -1,4 +1,4 @@
-// Probe: which XCC (XCD) runs workgroup i of a dispatch?  build: hipcc -O3 --offload-arch=gfx950 tools/xcc_probe.hip -o /tmp/xcc_probe
+// Probe: which XCC (XCD) runs workgroup i of a dispatch?  build: hipcc -O3 --offload-arch=gfx950 tools/probes/xcc_probe.hip -o /tmp/xcc_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 __global__ void k(int* out) {

@@ -9,7 +9,7 @@
 // workgroup, on another XCD, wrote in the previous phase and checks it: stale reads are counted), idle and BESIDE a second
 // stream that keeps every CU busy with an MFMA-bound kernel: the situation of the real step, where the weight gradients
 // and the deferred skip-window convs run beside the chain.
-// build + run (GPU box): hipcc -O3 --offload-arch=gfx950 tools/xcd_barrier_probe.hip -o /tmp/xcd_barrier_probe && /tmp/xcd_barrier_probe
+// build + run (GPU box): hipcc -O3 --offload-arch=gfx950 tools/probes/xcd_barrier_probe.hip -o /tmp/xcd_barrier_probe && /tmp/xcd_barrier_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1253,7 +1253,7 @@ static int run_narrow_wgrad(const wun_plan* p, NarrowWgradArgs* parts, int npart
     // bf16 mode, history (round 5): built WITH packed fp32 VALU instructions, narrow_wgrad_kernel (the LDS-staged
     // form: the output head, audio-input convs with < 4 taps) returned different accumulators from run to run whenever bf16 MFMA
     // kernels ran beside it; round 5 built the unit without them AND, as a second line, ran this launch alone on the caller's
-    // stream.  Round 6: tools/pk_fma_probe.hip reproduces the defect stand-alone (the compiler's packed instruction mix beside a
+    // stream.  Round 6: tools/probes/pk_fma_probe.hip reproduces the defect stand-alone (the compiler's packed instruction mix beside a
     // v_mfma_f32_16x16x32_bf16 spinner: 2085 of 10000 launches differ; alone, beside an fp32-MFMA spinner, or built without
     // packed ops: 0), the library with packed ops + overlap differs in 60 of 60 probe steps, the shipped build with overlap in
     // 0 of 600 -- so the launch is back on the side stream (~1 % of the bf16 step).  WUN_BF16_HEAD_SERIAL=1: round 5's placement.

@@ -1,7 +1,7 @@
 // gfx950: "register-window" form of the exact-fp32 weight / bias gradient (Training.py:77 backward of the convs of
 // UnetAudioSeparator.py:97-125):   dW[k][c][n] = sum_{b,q} x[b][c][S q + k - shift] * dz[b][n][q],   db[n] = sum dz.
 //
-// What the measurements of round 4 say about the fp32 matrix pipe (tools/mfma_power_probe.hip): a
+// What the measurements of round 4 say about the fp32 matrix pipe (tools/probes/mfma_power_probe.hip): a
 // dense v_mfma_f32_16x16x4_f32 stream fed by ALIGNED 16-byte LDS reads runs at 33.2 cycles per MFMA from one wave per
 // SIMD (32.3 from two); wgrad_mfma_kernel's stream -- one 4-byte LDS read per operand and k-step, rows at arbitrary
 // 4-byte alignment -- needs 36.5-37.6 whoever else shares the SIMD, and every VALU instruction of the staging code
@@ -14,7 +14,7 @@
 //    (the k index of an MFMA is a summation index: lane group lg takes positions 4 lg + s).  dz: one 16-byte read per
 //    column tile and block.  7 LDS reads per 96 MFMAs instead of 48 (K = 15, three column tiles).
 //  * the input window and the dz tile of a unit go global -> LDS by DMA (global_load_lds, 16 bytes per lane, source at
-//    any 4-byte alignment -- probed: tools/dma_align_probe): the LDS image starts exactly at the first sample the unit
+//    any 4-byte alignment -- probed: tools/probes/dma_align_probe): the LDS image starts exactly at the first sample the unit
 //    needs, so crop offsets / 'same' padding shifts cost nothing; no staging registers, no LDS stores, per unit a few
 //    DMA instructions with unit-invariant per-lane offsets; edge units clamp their addresses and zero the samples
 //    outside [0, Tin) / beyond Tq in LDS after landing.  Stride-2 convs need no de-interleave (window element 2 s + k).
