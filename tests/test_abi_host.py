@@ -241,7 +241,7 @@ def test_c_caller_links_and_runs(tmp_path):
 
 def test_bf16_mode_units_carry_no_packed_fp32_instructions():
     """tools/pk_check.sh on the objects libwun.so was linked from: the translation units whose kernels can run beside a bf16
-    MFMA kernel hold no v_pk_{fma,mul,add}_f32 / v_pk_mov_b32 (DESIGN.md 5g(9): the compiler's packed instruction mix returns
+    MFMA kernel hold no v_pk_{fma,mul,add}_f32 / v_pk_mov_b32 (DESIGN.md 5.3: the compiler's packed instruction mix returns
     different results from run to run beside v_mfma_f32_16x16x32_bf16 waves -- tools/probes/pk_fma_probe.hip,
     profiles/round6_pk_fma_probe.txt; a Makefile edit that drops the flag from one unit must fail here, not on the GPU)."""
     import subprocess

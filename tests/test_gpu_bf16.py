@@ -405,7 +405,7 @@ def test_m4_context_step_is_bit_reproducible_across_fresh_separators(lib, dtype)
     The bf16 mode's translation units are built without those instructions (csrc/Makefile NO_PK_FP32).  Round 6:
     2 x 1000 fresh-separator steps (M1 + context, M4) on that build bitwise identical, a stand-alone reproducer
     (tools/probes/pk_fma_probe.hip) and the overlap bisect are in profiles/round6_pk_fma_probe.txt / round6_repro_probe.txt;
-    DESIGN.md section 5g(9)."""
+    DESIGN.md section 5.3."""
     over = dict(output_type="difference", context=True, mono_downmix=False)
     ocfg = shapes.finalize_config(dict(shapes.BASE_MODEL_CONFIG, **over))
     params = golden_params(ocfg, 91)

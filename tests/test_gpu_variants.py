@@ -430,7 +430,13 @@ def test_every_conv_variant_was_exercised(lib):
     missing = [v for v in range(nvar) if v not in _RAN_CONV and v not in RETIRED_VARIANTS]
     assert not missing, "conv tile variants never checked: %s" % missing
     kinds = set().union(*_RAN_CONV.values())
-    assert kinds == {"stride1", "stride2", "two_source_accum_mask", "strided_output", "fused_two_phase"}, kinds
+    assert kinds == {"stride1", "stride2", "two_source_accum_mask", "strided_output", "fused_two_phase",
+                     "copies_expand_stride2", "copies_parity_split_masked", "copies_acc_window"}, kinds
+    # the round-6 epilogue features (secondary copies / windowed accumulate) ran on the plain, batch-folded and in-workgroup
+    # split-K tile families alike
+    for kind in ("copies_expand_stride2", "copies_parity_split_masked", "copies_acc_window"):
+        vs = sorted(v for v, k in _RAN_CONV.items() if kind in k)
+        assert len(vs) >= 20 and any(34 <= v <= 41 for v in vs) and any(v >= 56 for v in vs), (kind, vs)
     # every variant that can serve the fused two-phase launch (one wave column, even number of column
     # tiles, 8-channel chunks, not batch-folded) was checked there
     fused = sorted(v for v, k in _RAN_CONV.items() if "fused_two_phase" in k)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# ADVICE round 5 / DESIGN.md section 5g(9): the translation units whose kernels can run beside a bf16 MFMA kernel must contain NO
+# ADVICE round 5 / DESIGN.md section 5.3: the translation units whose kernels can run beside a bf16 MFMA kernel must contain NO
 # packed fp32 VALU instruction (v_pk_fma_f32, v_pk_mul_f32, v_pk_add_f32, v_pk_mov_b32): tools/probes/pk_fma_probe.hip shows the
 # compiler's packed instruction mix returning different results from run to run while v_mfma_f32_16x16x32_bf16 waves share the
 # CU (profiles/round6_pk_fma_probe.txt).  This check disassembles the OBJECTS the library is linked from (so it sees the flags

@@ -1,4 +1,4 @@
-// Stand-alone reproducer attempt for DESIGN.md 5g(9): do packed fp32 VALU instructions
+// Stand-alone reproducer for DESIGN.md 5.3: do packed fp32 VALU instructions
 // (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) return different results from run to run while waves of ANOTHER kernel stream
 // bf16 MFMAs (v_mfma_f32_16x16x32_bf16) on the same CUs?
 //

@@ -5,7 +5,7 @@ Runs a handful of small configurations first (process history: earlier plans, th
 the M4 configuration (BASELINE.json configs[2]: context + stereo + difference output, 147443 -> 16389 samples, B = 2) nine
 times on fresh separators and compares loss, outputs, every gradient tensor and every tensor the step leaves in the
 workspace (wun_plan_activation kinds 0 - 9) BITWISE with the first run.  This is the probe that found the bf16 mode's
-head weight gradient differing from run to run when wgrad_bf16_kernel ran beside narrow_wgrad_kernel (DESIGN.md 5g);
+head weight gradient differing from run to run when wgrad_bf16_kernel ran beside narrow_wgrad_kernel (DESIGN.md 5.3);
 (the library built WITH packed fp32 ops: make -C wave-u-net_amd/csrc pkdiag; WUN_LIB=libwun_pk.so shows the defect again; WUN_BF16_HEAD_SERIAL=1 is round 5's serialised placement).
 usage: python tools/repro_probe.py [bf16|f32] [m4|m4_same|m1_context|m5|multi|multi_direct]"""
 import os, sys

@@ -1250,7 +1250,7 @@ static int run_narrow_wgrad(const wun_plan* p, NarrowWgradArgs* parts, int npart
                             const long long* boff, float* ws, float* grads, hipStream_t main, hipStream_t s) {
     int rcd = WUN_OK;
     hipStream_t side_of_caller = s;                            // (bucket events of the data-parallel path are recorded there)
-    // bf16 mode, history (round 5, DESIGN 5g(9)): built WITH packed fp32 VALU instructions, narrow_wgrad_kernel (the LDS-staged
+    // bf16 mode, history (round 5, DESIGN 5.3): built WITH packed fp32 VALU instructions, narrow_wgrad_kernel (the LDS-staged
     // form: the output head, audio-input convs with < 4 taps) returned different accumulators from run to run whenever bf16 MFMA
     // kernels ran beside it; round 5 built the unit without them AND, as a second line, ran this launch alone on the caller's
     // stream.  Round 6: tools/probes/pk_fma_probe.hip reproduces the defect stand-alone (the compiler's packed instruction mix beside a
