@@ -1431,7 +1431,8 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
         //  contiguous 32-byte stores instead of two stride-2 scatter passes)
         // (the odd-window launches fuse from 64 workgroups / 64 output pairs on: they run on the side streams, where one
         //  launch beats two phase launches + two split-K epilogues; WUN_ODD_FUSE_MIN overrides the floor)
-        static const int odd_min = getenv("WUN_ODD_FUSE_MIN") ? atoi(getenv("WUN_ODD_FUSE_MIN")) : 64;
+        const char* of_env = getenv("WUN_ODD_FUSE_MIN");
+        const int odd_min = of_env ? atoi(of_env) : 64;
         const int tmin = odd ? std::min(256, odd_min) : 256, wmin = odd ? odd_min : 256;
         if ((d.cin & 3) == 0 && (p->bf16 || (f.Tout >= tmin && conv_natural_wgs_phase2(f) >= wmin))) {
             HIP_TRY(conv_dispatch(p, f, part, cap, st));
