@@ -29,6 +29,14 @@
  * is (the last internal operation of every call is the caller's stream waiting for the side streams); host code
  * synchronises through that stream, never through the plan's events.
  *
+ * Concurrency caveat (measured on MI355X, tools/probes/pk_fma_probe.hip): a packed fp32 FMA whose low lane
+ * reads the high half of a register pair (v_pk_fma_f32 ... op_sel:[0,1,0], which the compiler emits freely) returns wrong
+ * results while ANOTHER kernel's v_mfma_f32_16x16x32_bf16 waves share the CU.  Every kernel of the bf16 mode, and every kernel
+ * both modes share, is built without packed fp32 instructions; the exact-fp32 MFMA kernels keep them (0.5 % per step) because
+ * inside one plan they only ever run beside fp32 MFMA kernels.  Do not RUN an exact-fp32 plan concurrently (other stream /
+ * thread, same device) with a bf16-mode plan or with other bf16-MFMA work (e.g. a bf16 GEMM); back to back is fine.
+ * `make -C wave-u-net_amd/csrc nopkall` builds a library without any packed fp32 instruction for callers who must.
+ *
  * Tensor layouts at the boundary are the reference's: audio is float32 [B, T, C]
  * (channel-last, exactly what get_output receives/returns); kernels are TF layout
  * [K, Cin, Cout]; variables sit in a flat float32 arena in TF creation order
