@@ -7,8 +7,9 @@ conv AND a full-rate conv over the skip window (rounds 1 - 5: the even window po
 * the forward activations the new plan leaves in the workspace: the skip window's even positions hold THE SAME BITS as the
   decimated stream (one value, one rounding);
 * every schedule of the odd-window input gradients (`WUN_EARLY_WINDOW` = default (all levels early on the side streams) / deep /
-  0 (none early: the non-nested fall-back path, window part after the row-wide part)) and both fuse floors give the same
-  gradients to fp32 summation order (a + b + c in another order);
+  0 (none early: the non-nested fall-back path, window part after the row-wide part)), both fuse floors and both forms of the
+  fused odd-window launch (aligned start with the shifted filter / odd start, `WUN_NO_ODD_ALIGN`) give the same gradients to fp32
+  summation order (a + b + c in another order);
 * odd and even crop starts, levels whose window has a single position, stereo / difference / learned-upsampling heads.
 """
 import numpy as np
@@ -39,7 +40,7 @@ TOL_PLANS = 5e-4  # ... between the two PLANS: the old one rounds the even windo
 
 
 def _run(cfg, batch, env, monkeypatch, want_acts=False):
-    for k in ("WUN_NO_DEDUP", "WUN_EARLY_WINDOW", "WUN_ODD_FUSE_MIN"):
+    for k in ("WUN_NO_DEDUP", "WUN_EARLY_WINDOW", "WUN_ODD_FUSE_MIN", "WUN_NO_ODD_ALIGN"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -106,7 +107,8 @@ def test_every_schedule_of_the_odd_window_gradients_gives_the_same_network(case,
     ref = _run(cfg, batch, {}, monkeypatch)
     worst = 0.0
     for env in ({"WUN_EARLY_WINDOW": "deep"}, {"WUN_EARLY_WINDOW": "0"}, {"WUN_ODD_FUSE_MIN": "256"},
-                {"WUN_ODD_FUSE_MIN": "1"}, {"WUN_EARLY_WINDOW": "0", "WUN_ODD_FUSE_MIN": "1"}):
+                {"WUN_ODD_FUSE_MIN": "1"}, {"WUN_EARLY_WINDOW": "0", "WUN_ODD_FUSE_MIN": "1"},
+                {"WUN_NO_ODD_ALIGN": "1"}, {"WUN_NO_ODD_ALIGN": "1", "WUN_ODD_FUSE_MIN": "1", "WUN_EARLY_WINDOW": "0"}):
         got = _run(cfg, batch, env, monkeypatch)
         worst = max(worst, _close(got, ref, str(env)))
     record("dedup_schedule_modes_gradients", "%s %s" % (name, sorted(over.items())), worst, TOL)

@@ -97,7 +97,11 @@ extern "C" int wun_get_padding(const wun_config* cfg, int64_t desired, int64_t* 
 // mode) elements; `off` is in FLOATS from the workspace base, pitch and bs are in ELEMENTS; rows are 16-byte aligned.
 struct Buf { long long off = -1; int C = 0; int T = 0; int pitch = 0; long long bs = 0; int eb = 4; };
 struct ConvLayer { long long woff = 0, boff = 0; int KW = 0, Cin = 0, Cout = 0;
-                   long long wt_full = -1, wt_ph[2] = {-1, -1}, wt_ph2 = -1; int Jp[2] = {0, 0}; int J0 = 0; };
+                   long long wt_full = -1, wt_ph[2] = {-1, -1}, wt_ph2 = -1; int Jp[2] = {0, 0}; int J0 = 0;
+                   // dedup plans: the two-phase image of the filter SHIFTED by one tap (W''[k + 1] = W[k], W''[0] = 0), for the
+                   // odd-window input gradient: its outputs start at an odd row position; with the shifted filter the launch
+                   // starts one position earlier, on a 16-byte boundary, and takes the vector epilogue
+                   long long wt_ph2s = -1; int J0s = 0; };
 // tc / cs: length / start of the centre crop the skip connection takes (Utils.py:104-123), in conv-output positions.
 // Round 6 (dedup plans): the crop window split by the parity of the ABSOLUTE conv position -- even positions are elements
 // of the decimated stream (computed once, by the stride-2 launch), odd positions get their own stride-2 launches:
@@ -431,6 +435,11 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
             }
             cl.J0 = (cl.KW + 1) / 2;
             cl.wt_ph2 = add_wt2(cl, cl.J0);
+            if (p->dedup) {
+                cl.J0s = (cl.KW + 2) / 2;
+                cl.wt_ph2s = add_wt2(cl, cl.J0s);
+                p->wt.back().k_last = 2 * (cl.J0s - 1) - 1;      // tap of W behind tap 2 (J0s - 1) of the shifted filter
+            }
         }
     }
     p->bott.wt_full = add_wt(p->bott, Kd, Kd - 1, 1);
@@ -1427,6 +1436,21 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
         f.N = f.N0 = d.cin; f.Tout = (out_len + 1) / 2; f.Tlim = out_len; f.flags = F_PHASE2;
         set_dst0(f, ws, p->dz_dec[i - 1], out_off, &p->dec[i - 1]);
         if (accum) { f.flags |= F_ACCUM; f.acc_lo = acc_lo; f.acc_len = acc_len; }
+        // Odd-window part: its outputs start at the odd row position t_odd0 -- scalar read-modify-write stores.  With the
+        // filter shifted by one tap (wt_ph2s: the same sums, one leading zero tap) the launch starts at t_odd0 - 1, and -- one
+        // more (zero) input position in front when that is not a multiple of 4 -- at t_odd0 - 3: a 16-byte boundary, the vector
+        // epilogue.  The leading outputs it adds are sums over zero taps / positions before the first sample: +0 where it
+        // accumulates, 0 where it stores (positions the row-wide conv then stores over: they lie outside its accumulate range).
+        const bool no_align = getenv("WUN_NO_ODD_ALIGN") != nullptr;
+        if (odd && cl.wt_ph2s >= 0 && !no_align) {
+            const int base = d.t_odd0 - 1, extra = (base & 3) ? 2 : 0;
+            if (base - extra >= 0) {
+                f.KW = cl.J0s; f.shift = cl.J0s - 1 + (extra ? 1 : 0); f.W = ws + cl.wt_ph2s;
+                const int len2 = out_len + 1 + extra;
+                f.Tout = (len2 + 1) / 2; f.Tlim = len2;
+                set_dst0(f, ws, p->dz_dec[i - 1], base - extra, &p->dec[i - 1]);
+            }
+        }
         // (bf16 mode: always fused when the channel count allows -- one launch, the gradient tile staged once,
         //  contiguous 32-byte stores instead of two stride-2 scatter passes)
         // (the odd-window launches fuse from 64 workgroups / 64 output pairs on: they run on the side streams, where one
@@ -1792,6 +1816,7 @@ static std::string tune_header(const wun_plan* p, size_t ncf, size_t ncb, size_t
         if (ew[0] == 'd' && p->dedup) h += " ew=deep";
     }
     if (const char* of = getenv("WUN_ODD_FUSE_MIN")) h += std::string(" oddfuse=") + of;
+    if (getenv("WUN_NO_ODD_ALIGN") != nullptr && p->dedup) h += " oddalign=0";
     if (!p->same && !p->bf16 && !p->dedup) h += " dedup=0";       // (WUN_NO_DEDUP=1: rounds 1 - 5's launch sequence)
     return h;
 }
