@@ -169,6 +169,7 @@ struct UpsampleBwdArgs {
     const float* x; long long xbs; int xpitch; int n;      // forward input (post-activation)
     float* dz;                                             // out: dL/d(pre-activation of x), geometry of x
     const float* w; float* dw;                             // interp weights / their gradient (or null)
+    float* dw_partial;                                     // [B][C] scratch of the two-stage interp-weight gradient (or null: one workgroup per channel)
     int C; int B; int context;
     int bf;                                                // dy, x and dz hold bf16 elements
 };

@@ -143,6 +143,7 @@ struct wun_plan {
     long long dpre_off = -1; int dp_pitch = 0;
     long long partial_off = -1, partial_floats = 0;
     long long loss_partial_off = -1;
+    long long interp_partial_off = -1;
     long long conv_part_off = -1, conv_part_floats = 0;
     std::vector<WtDesc> wt;
     WtDesc* dev_wt = nullptr;
@@ -401,6 +402,7 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
         }
     }
     p->loss_partial_off = bump(w, 1024);
+    if (cfg->upsampling == 1) p->interp_partial_off = bump(w, (long long)B * p->c_b);      // [B][C] partials of an interp_<j> gradient
     p->conv_part_floats = 16ll << 20;                       // split-K scratch (64 MiB)
     p->conv_part_off = bump(w, p->conv_part_floats);
 
@@ -1634,6 +1636,7 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
             ub.dz = ws + dzprev.off;
             ub.w = p->interp[j] >= 0 ? params + p->interp[j] : nullptr;
             ub.dw = p->interp[j] >= 0 ? grads + p->interp[j] : nullptr;
+            ub.dw_partial = (p->interp[j] >= 0 && p->interp_partial_off >= 0) ? ws + p->interp_partial_off : nullptr;
             ub.C = u.c_cur; ub.B = p->B; ub.context = p->cfg.context; ub.bf = p->bf16 ? 1 : 0;
             HIP_TRY(launch_upsample_bwd(ub, s));
         }
