@@ -319,9 +319,17 @@ hipError_t launch_upsample_bwd(const UpsampleBwdArgs& a, hipStream_t s) {
         if (a.bf) hipLaunchKernelGGL(upsample_bwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, a);
         else hipLaunchKernelGGL(upsample_bwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, a);
     }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+// gradient of the learned interpolation weights of one level (InterpolationLayer.py:19-23): reads d(upsampled tensor) and the
+// level's input, writes dw -- nothing the input-gradient chain waits for, so the plan runs it on a side stream
+hipError_t launch_interp_grad(const UpsampleBwdArgs& a, hipStream_t s) {
+    hipError_t e = hipSuccess;
+    const bool vecok = (a.ypitch & 3) == 0 && (a.ybs & 3) == 0 && (reinterpret_cast<uintptr_t>(a.dy) & 15) == 0 &&
+                       (a.xpitch & 3) == 0 && (a.xbs & 3) == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
     if (a.w != nullptr && a.dw != nullptr) {
+        ProfScope ps("interp_grad_kernel", 0.0, s, "", (a.bf ? 2.0 : 4.0) * (double)a.B * a.C * (a.n + a.tup));
         // rows 16-byte aligned (the plan's buffers) and a scratch vector given: the two-stage form
         if (a.dw_partial != nullptr && vecok && a.B <= 65535) {
             const dim3 grid((unsigned)a.C, (unsigned)a.B);

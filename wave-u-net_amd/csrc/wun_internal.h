@@ -258,6 +258,7 @@ hipError_t launch_wgrad_reduce(const WgradArgs& a, const float* partial, int nsp
                                hipStream_t s);
 hipError_t launch_upsample(const UpsampleArgs& a, hipStream_t s);
 hipError_t launch_upsample_bwd(const UpsampleBwdArgs& a, hipStream_t s);
+hipError_t launch_interp_grad(const UpsampleBwdArgs& a, hipStream_t s);               // dw of the learned interpolation weights
 hipError_t launch_head_fwd_off(const HeadArgs& a, const long long* hoff, hipStream_t s);
 int head_bwd_blocks(const HeadArgs& a);
 hipError_t launch_head_bwd_off(const HeadArgs& a, const long long* hoff, hipStream_t s);

@@ -143,7 +143,7 @@ struct wun_plan {
     long long dpre_off = -1; int dp_pitch = 0;
     long long partial_off = -1, partial_floats = 0;
     long long loss_partial_off = -1;
-    long long interp_partial_off = -1;
+    std::vector<long long> interp_partial_off;
     long long conv_part_off = -1, conv_part_floats = 0;
     std::vector<WtDesc> wt;
     WtDesc* dev_wt = nullptr;
@@ -402,7 +402,10 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
         }
     }
     p->loss_partial_off = bump(w, 1024);
-    if (cfg->upsampling == 1) p->interp_partial_off = bump(w, (long long)B * p->c_b);      // [B][C] partials of an interp_<j> gradient
+    if (cfg->upsampling == 1) {                                   // [B][C] partials of every interp_<j> gradient (own block per
+        p->interp_partial_off.assign(L, -1);                      // level: consecutive levels run on different side streams)
+        for (int j = 0; j < L; ++j) p->interp_partial_off[j] = bump(w, (long long)B * p->ush[j].c_cur);
+    }
     p->conv_part_floats = 16ll << 20;                       // split-K scratch (64 MiB)
     p->conv_part_off = bump(w, p->conv_part_floats);
 
@@ -1409,6 +1412,7 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
             if (!e) HIP_TRY(hipEventCreateWithFlags(&e, event_flags()));
     }
     std::vector<int> pend_win;
+    std::vector<UpsampleBwdArgs> pend_interp;
     const long long cpart_half = p->conv_part_floats / 2, cpart_q = p->conv_part_floats / 4;
     auto window_dgrad_args = [&](int i) {
         const DownShape& d = p->dsh[i];
@@ -1477,13 +1481,15 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
         return WUN_OK;
     };
     auto flush_wgrads = [&]() -> int {
-        if (pend.empty() && pend_win.empty()) return WUN_OK;
+        if (pend.empty() && pend_win.empty() && pend_interp.empty()) return WUN_OK;
         if (s2 != s) {
             hipEvent_t e = p->events[p->ev_next++ % p->events.size()];
             HIP_TRY(hipEventRecord(e, s));
             HIP_TRY(hipStreamWaitEvent(s2, e, 0));
             if (s3 != s2) HIP_TRY(hipStreamWaitEvent(s3, e, 0));
         }
+        for (auto& ub : pend_interp) HIP_TRY(launch_interp_grad(ub, wstream()));
+        pend_interp.clear();
         for (auto& q : pend) {
             int rcq = run_wgrad(p, q.w, q.n, *q.cl, ws, grads, s, wstream(), false);
             if (rcq) return rcq;
@@ -1636,9 +1642,12 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
             ub.dz = ws + dzprev.off;
             ub.w = p->interp[j] >= 0 ? params + p->interp[j] : nullptr;
             ub.dw = p->interp[j] >= 0 ? grads + p->interp[j] : nullptr;
-            ub.dw_partial = (p->interp[j] >= 0 && p->interp_partial_off >= 0) ? ws + p->interp_partial_off : nullptr;
+            ub.dw_partial = (p->interp[j] >= 0 && !p->interp_partial_off.empty()) ? ws + p->interp_partial_off[(size_t)j] : nullptr;
             ub.C = u.c_cur; ub.B = p->B; ub.context = p->cfg.context; ub.bf = p->bf16 ? 1 : 0;
             HIP_TRY(launch_upsample_bwd(ub, s));
+            // the interpolation weights' gradient is nobody's input on the chain: with the next flush, on a side stream
+            // (interp_<j> lies just below up[j]'s kernel in the arena: complete before the next layer's bucket signal)
+            if (ub.dw != nullptr) pend_interp.push_back(ub);
         }
     }
 
