@@ -51,6 +51,7 @@ struct ConvArgs {
     //                 stream's gradient, the other feeds the odd-position launches).
     int dec_exp; int dec_lo; unsigned dec_len;
     float* dec1; long long dec1bs; int dec1pitch;
+    int dec_off, dec1_off;       // first element of the copies inside their rows, in ELEMENTS of the copy's tensor (fp32 or bf16)
     int flags;
     int B;
     int loader;

@@ -201,7 +201,7 @@ __device__ __forceinline__ int fast_div(int n, int d, float inv) {
 // copies of a dst0 output element / quad beside its main store (ConvArgs.dec / dec_exp / dec1): b = excerpt, n = dst0 channel
 __device__ __forceinline__ void conv_copy1(const ConvArgs& a, int b, int n, int q, float v) {
     if (a.dec != nullptr) {
-        float* row = a.dec + (long long)b * a.decbs + (long long)n * a.decpitch;
+        float* row = a.dec + (long long)b * a.decbs + (long long)n * a.decpitch + a.dec_off;
         if (a.dec_exp) {
             const unsigned pos = (unsigned)(2 * q - a.dec_lo);
             if (pos < a.dec_len) row[pos] = v;
@@ -209,11 +209,11 @@ __device__ __forceinline__ void conv_copy1(const ConvArgs& a, int b, int n, int 
             row[q >> 1] = v;
         }
     }
-    if (a.dec1 != nullptr && (q & 1) != 0) a.dec1[(long long)b * a.dec1bs + (long long)n * a.dec1pitch + (q >> 1)] = v;
+    if (a.dec1 != nullptr && (q & 1) != 0) a.dec1[(long long)b * a.dec1bs + (long long)n * a.dec1pitch + a.dec1_off + (q >> 1)] = v;
 }
 __device__ __forceinline__ void conv_copy4(const ConvArgs& a, int b, int n, int q, f32x4 v) {       // q % 4 == 0, all four valid
     if (a.dec != nullptr) {
-        float* row = a.dec + (long long)b * a.decbs + (long long)n * a.decpitch;
+        float* row = a.dec + (long long)b * a.decbs + (long long)n * a.decpitch + a.dec_off;
         if (a.dec_exp) {
             const int pos0 = 2 * q - a.dec_lo;
 #pragma unroll
@@ -225,7 +225,7 @@ __device__ __forceinline__ void conv_copy4(const ConvArgs& a, int b, int n, int 
         }
     }
     if (a.dec1 != nullptr) {
-        float* row = a.dec1 + (long long)b * a.dec1bs + (long long)n * a.dec1pitch;
+        float* row = a.dec1 + (long long)b * a.dec1bs + (long long)n * a.dec1pitch + a.dec1_off;
         row[q >> 1] = v[1];
         row[(q >> 1) + 1] = v[3];
     }

@@ -366,6 +366,10 @@ extern "C" int wun_plan_create(const wun_config* cfg, int64_t batch, int64_t inp
     // d(pre-activation), weights, weight gradients and all scratch stay fp32)
     p->bf16 = cfg->compute_dtype == 1 && bf16_plan_ok(cfg, B, p->dsh, p->t_b, p->ush, p->c_b, p->Sh);
     const int eb = p->bf16 ? 2 : 4;
+    // (exact-fp32 mode only.  The bf16 mode was built and measured with it at the end of round 6 -- bf16 epilogues with the
+    //  expanded / parity copies, the audio-input conv with a strided output, the emulation restated; all 62 bf16-mode tests
+    //  green -- and was 3 - 4 % SLOWER (M4 3.27 -> 3.39 ms): its kernels are bound by the instruction stream around the MFMAs,
+    //  the scalar strided epilogues of the odd-position launches cost more than the halved window work saves.  Not adopted.)
     p->dedup = !same && !p->bf16 && getenv("WUN_NO_DEDUP") == nullptr;
     p->mix_ncw = make_buf(w, B, C, p->Tin, "mix_ncw");
     p->dec.resize(L); p->skip.resize(L); p->dz_dec.resize(L); p->dz_skip.resize(L);
@@ -1612,13 +1616,13 @@ extern "C" int wun_loss_backward_ex(const wun_plan* p, const float* params, cons
                 // window element q sits at absolute conv position cs + q: the even positions are elements of the decimated
                 // stream -- their gradient goes into dz_dec[i] (index (cs + q) / 2), the odd ones compact into dz_odd[i]
                 const DownShape& d = p->dsh[i];
-                float* ev = ws + p->dz_dec[i].off + d.t_ev0 / 2;
+                float* ev = ws + p->dz_dec[i].off;
                 float* od = ws + p->dz_odd[i].off;
                 const bool cs_even = (d.cs & 1) == 0;
                 a.dec = cs_even ? ev : od;  a.decbs = cs_even ? p->dz_dec[i].bs : p->dz_odd[i].bs;
-                a.decpitch = cs_even ? p->dz_dec[i].pitch : p->dz_odd[i].pitch;
+                a.decpitch = cs_even ? p->dz_dec[i].pitch : p->dz_odd[i].pitch; a.dec_off = cs_even ? d.t_ev0 / 2 : 0;
                 a.dec1 = cs_even ? od : ev; a.dec1bs = cs_even ? p->dz_odd[i].bs : p->dz_dec[i].bs;
-                a.dec1pitch = cs_even ? p->dz_odd[i].pitch : p->dz_dec[i].pitch;
+                a.dec1pitch = cs_even ? p->dz_odd[i].pitch : p->dz_dec[i].pitch; a.dec1_off = cs_even ? 0 : d.t_ev0 / 2;
             }
             const Buf& prev = (j == 0) ? p->bott_out : p->upo[j - 1];
             const Buf& dzprev = (j == 0) ? p->dz_bott : p->dz_upo[j - 1];
